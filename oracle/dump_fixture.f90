@@ -1,0 +1,161 @@
+! TEST INFRASTRUCTURE ONLY (oracle) -- compiled only in the build container, never shipped.
+!
+! Fixture generator: links against the *compiled reference modules* (oracle/_ref/librslmto_ref.a,
+! built by oracle/build_ref.sh from the sources where they lie) and replays the reference's own
+! set-up sequence up to the recursion call, then runs the reference recursion driver and writes
+! the recursion's INPUTS (lattice tables + Hamiltonian blocks) and OUTPUTS (coefficients/moments)
+! at full precision to a stream file `fixture.bin`.
+!
+! Sequence mirrored (call order only; all arithmetic is the reference's own compiled code):
+!   calculation.f90:550-611  (pre_processing_bravais),  :475-543 (buildsurf),
+!   calculation.f90:320-390  (newclubulk),              :397-468 (newclusurf)
+!   self.f90:769-806         (run_recursion: build_pot / build_lsham / build_bulkham / build_locham,
+!                             then recur | recur_b | chebyshev_recur)
+! Run it inside a scratch copy of a case directory (input.nml + <label>.nml): it reads input.nml.
+program dump_fixture
+   use mpi_mod
+   use control_mod
+   use lattice_mod
+   use charge_mod
+   use mix_mod
+   use energy_mod
+   use hamiltonian_mod
+   use recursion_mod
+   use density_of_states_mod
+   use green_mod
+   use bands_mod
+   use self_mod
+   use calculation_mod
+   use precision_mod, only: rp
+   use timer_mod, only: g_timer, timer
+   use logger_mod, only: g_logger
+   implicit none
+
+   type(calculation) :: calc_obj
+   type(control), target :: control_obj
+   type(lattice), target :: lattice_obj
+   type(energy), target :: energy_obj
+   type(charge), target :: charge_obj
+   type(hamiltonian), target :: hamiltonian_obj
+   type(recursion), target :: recursion_obj
+   type(mix), target :: mix_obj
+   integer :: ia, u, kind_rec, nslots, hoh_i, nsites, ncheb
+   real(rp) :: acheb, bcheb
+   character(len=32) :: pre
+
+   rank = 0
+   numprocs = 1
+   g_timer = timer()
+
+   calc_obj = calculation('input.nml')
+   pre = trim(calc_obj%pre_processing)
+
+   control_obj = control('input.nml')
+   lattice_obj = lattice(control_obj)
+   call lattice_obj%build_data()
+   call lattice_obj%bravais()
+   select case (trim(pre))
+   case ('bravais')
+      call lattice_obj%structb(.true.)
+   case ('buildsurf')
+      call lattice_obj%build_surf_full()
+      call lattice_obj%structb(.true.)
+   case ('newclubulk')
+      call lattice_obj%newclu()
+      call lattice_obj%structb(.true.)
+   case ('newclusurf')
+      call lattice_obj%build_surf_full()
+      call lattice_obj%newclu()
+      call lattice_obj%structb(.true.)
+   case default
+      stop 'dump_fixture: unsupported pre_processing'
+   end select
+   call lattice_obj%atomlist()
+   call get_mpi_variables(rank, lattice_obj%nrec)
+
+   charge_obj = charge(lattice_obj)
+   select case (trim(pre))
+   case ('bravais')
+      call charge_obj%bulkmat()
+   case ('buildsurf')
+      call charge_obj%build_alelay
+      call charge_obj%surfmat
+   case default
+      call charge_obj%impmad()
+      call charge_obj%get_charge_transf
+   end select
+
+   mix_obj = mix(lattice_obj, charge_obj)
+   energy_obj = energy(lattice_obj)
+   hamiltonian_obj = hamiltonian(charge_obj)
+   recursion_obj = recursion(hamiltonian_obj, energy_obj)
+
+   ! ---- self.f90:769-797 (run_recursion, operator set-up part)
+   select case (control_obj%calctype)
+   case ('B')
+      do ia = 1, lattice_obj%nrec
+         call lattice_obj%symbolic_atoms(ia)%build_pot()
+      end do
+   case default
+      do ia = 1, lattice_obj%ntype
+         call lattice_obj%symbolic_atoms(ia)%build_pot()
+      end do
+   end select
+   if (control_obj%nsp == 2 .or. control_obj%nsp == 4) call hamiltonian_obj%build_lsham
+   call hamiltonian_obj%build_bulkham()
+   if (control_obj%calctype == 'I') call hamiltonian_obj%build_locham()
+
+   ! ---- self.f90:799-806 (the recursion itself = the hot path under test)
+   select case (trim(control_obj%recur))
+   case ('lanczos')
+      kind_rec = 2
+      call recursion_obj%recur()
+   case ('chebyshev')
+      kind_rec = 1
+      call recursion_obj%chebyshev_recur()
+   case ('block')
+      kind_rec = 0
+      call recursion_obj%recur_b()
+   case default
+      stop 'dump_fixture: unsupported recur'
+   end select
+
+   nslots = size(hamiltonian_obj%ee, 3)
+   hoh_i = 0
+   if (hamiltonian_obj%hoh) hoh_i = 1
+   nsites = lattice_obj%nrec
+   ncheb = 2*control_obj%lld + 2
+   acheb = (energy_obj%energy_max - energy_obj%energy_min)/(2 - 0.3)
+   bcheb = (energy_obj%energy_max + energy_obj%energy_min)/2
+
+   open (newunit=u, file='fixture.bin', access='stream', form='unformatted', status='replace')
+   write (u) int(z'52534658'), 1
+   write (u) lattice_obj%kk, size(lattice_obj%nn, 2), lattice_obj%nmax, lattice_obj%ntype, lattice_obj%nrec, &
+      control_obj%lld, control_obj%nsp, hoh_i, kind_rec, nslots, size(recursion_obj%a, 1)
+   write (u) energy_obj%energy_min, energy_obj%energy_max, acheb, bcheb
+   write (u) lattice_obj%iz(1:lattice_obj%kk)
+   write (u) lattice_obj%nn
+   write (u) lattice_obj%irec(1:lattice_obj%nrec)
+   write (u) lattice_obj%cr(1:3, 1:lattice_obj%kk)
+   write (u) hamiltonian_obj%ee
+   write (u) hamiltonian_obj%lsham
+   write (u) hamiltonian_obj%eeo
+   write (u) hamiltonian_obj%enim
+   if (lattice_obj%nmax > 0) then
+      write (u) hamiltonian_obj%hall
+      write (u) hamiltonian_obj%hallo
+   end if
+   select case (kind_rec)
+   case (0)
+      write (u) recursion_obj%a_b
+      write (u) recursion_obj%b2_b
+   case (1)
+      write (u) recursion_obj%mu_n
+   case (2)
+      write (u) recursion_obj%a(:, :, :, 1)
+      write (u) recursion_obj%b2(:, :, :, 1)
+   end select
+   close (u)
+   write (*, *) 'dump_fixture: wrote fixture.bin kk=', lattice_obj%kk, ' nmax=', lattice_obj%nmax, ' nrec=', lattice_obj%nrec, &
+      ' lld=', control_obj%lld, ' nslots=', nslots, ' kind=', kind_rec, ' hoh=', hoh_i
+end program dump_fixture

@@ -1,0 +1,109 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes front-end of the CPU oracle (oracle/rsrec_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It is the checker for the HIP path and is never used to produce a product result.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "librsrec_oracle.so")
+
+
+class _Problem(C.Structure):
+    _fields_ = [("kk", C.c_int), ("nncols", C.c_int), ("nmax", C.c_int), ("ntype", C.c_int), ("nslots", C.c_int),
+                ("hoh", C.c_int), ("nsp", C.c_int),
+                ("nn", C.c_void_p), ("iz", C.c_void_p),
+                ("ee", C.c_void_p), ("lsham", C.c_void_p), ("eeo", C.c_void_p), ("enim", C.c_void_p),
+                ("hall", C.c_void_p), ("hallo", C.c_void_p)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rsrec_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librsrec_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _f(a, dtype):
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+class Oracle:
+    """Holds one problem (lattice tables + Hamiltonian blocks) for the CPU oracle."""
+
+    def __init__(self, p):
+        self.keep = {}
+        nn = self.keep["nn"] = _f(p["nn"], np.int32)
+        self.kk, self.nncols = nn.shape
+        ee = self.keep["ee"] = _f(p["ee"], np.complex128)
+        self.nslots, self.ntype = ee.shape[2], ee.shape[3]
+        self.nmax = int(p.get("nmax", 0))
+        self.hoh = int(p.get("hoh", 0))
+        self.nsp = int(p.get("nsp", 2))
+        self.keep["iz"] = _f(p["iz"], np.int32)
+        zt = np.zeros((18, 18, self.ntype), np.complex128, order="F")
+        self.keep["lsham"] = _f(p.get("lsham", zt), np.complex128)
+        self.keep["enim"] = _f(p.get("enim", zt), np.complex128)
+        self.keep["eeo"] = _f(p.get("eeo", np.zeros_like(ee)), np.complex128)
+        if self.nmax > 0:
+            self.keep["hall"] = _f(p["hall"], np.complex128)
+            self.keep["hallo"] = _f(p.get("hallo", np.zeros_like(self.keep["hall"])), np.complex128)
+        ptr = lambda k: self.keep[k].ctypes.data if k in self.keep else None
+        self.P = _Problem(self.kk, self.nncols, self.nmax, self.ntype, self.nslots, self.hoh, self.nsp,
+                          ptr("nn"), ptr("iz"), ptr("ee"), ptr("lsham"), ptr("eeo"), ptr("enim"), ptr("hall"), ptr("hallo"))
+
+    def block_lanczos(self, seeds, lld):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        n = len(seeds)
+        a_b = np.zeros((18, 18, lld, n), np.complex128, order="F")
+        b2_b = np.zeros_like(a_b)
+        rc = lib().orc_block_lanczos(C.byref(self.P), n, seeds.ctypes.data_as(C.c_void_p), lld,
+                                     a_b.ctypes.data_as(C.c_void_p), b2_b.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return a_b, b2_b
+
+    def chebyshev(self, seeds, lld, a, b):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        n = len(seeds)
+        mu = np.zeros((18, 18, 2 * lld + 2, n), np.complex128, order="F")
+        rc = lib().orc_chebyshev(C.byref(self.P), n, seeds.ctypes.data_as(C.c_void_p), lld, C.c_double(a), C.c_double(b),
+                                 mu.ctypes.data_as(C.c_void_p))
+        return mu, rc
+
+    def scalar_lanczos(self, seeds, lld, llmax=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        n = len(seeds)
+        llmax = llmax or lld
+        a = np.zeros((llmax, 18, n), np.float64, order="F")
+        b2 = np.zeros_like(a)
+        rc = lib().orc_scalar_lanczos(C.byref(self.P), n, seeds.ctypes.data_as(C.c_void_p), lld, llmax,
+                                      a.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return a, b2
+
+
+def zsqr(b2_b):
+    out = np.array(b2_b, dtype=np.complex128, order="F", copy=True)
+    nmat = out.size // 324
+    lib().orc_zsqr(nmat, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def site_partition(rank, nprocs, nsites):
+    s, e = C.c_int(), C.c_int()
+    lib().orc_site_partition(rank, nprocs, nsites, C.byref(s), C.byref(e))
+    return s.value, e.value
