@@ -1,0 +1,112 @@
+/* rsrec.h -- C ABI of librsrec: the MI355X (gfx950) recursion engine for RS-LMTO-ASA.
+ *
+ * Drop-in boundary for ONE hot path of rslmtoasa/rslmtoasa: the Haydock / block-Lanczos /
+ * Chebyshev recursion of source/recursion.f90.  The reference has no FFI today (it is 100 %
+ * Fortran); these entry points are what a `bind(C)` interface block in a replacement
+ * `recursion_mod` binds (see fortran/rsrec_binding.f90 and INTEGRATION.md).  Each entry point
+ * cites the reference procedure it replaces.
+ *
+ * Conventions (all follow the reference so Fortran arrays are passed as they are):
+ *   - every array is caller-allocated HOST memory in Fortran (column-major) order;
+ *   - complex(8) data are passed as `const double*` pointing at interleaved (re,im) pairs,
+ *     i.e. exactly Fortran `complex(rp)` / C `double _Complex` storage;
+ *   - atom numbers are 1-based, 0 = "no neighbour" (lattice.f90:1854, nn(kk, nnmax+1));
+ *   - every function returns 0 on success, non-zero on error; the message is read with
+ *     rsrec_last_error().  The Fortran shim turns non-zero into g_logger%fatal, which is the
+ *     reference's only error behaviour on this path (recursion.f90:1942, :2595).
+ *   - one handle per process/GPU; not re-entrant (like the reference's `this%` scratch).
+ *   - there is NO CPU fallback: rsrec_create fails if no gfx950 device is usable.
+ */
+#ifndef RSREC_H
+#define RSREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsrec_handle rsrec_t;
+
+#define RSREC_OK 0
+#define RSREC_ERR_ARG 1        /* bad argument / call order */
+#define RSREC_ERR_DEVICE 2     /* HIP runtime error (no device, out of memory, launch failure) */
+#define RSREC_ERR_DIVERGED 3   /* Chebyshev moments blew up: recursion.f90:2594-2596 (fatal in the reference) */
+#define RSREC_ERR_EIG 4        /* 18x18 eigen-solve did not converge: recursion.f90:1942 (zheev info /= 0) */
+
+/* Library/ABI version (major*100 + minor). */
+int rsrec_version(void);
+
+/* Create / destroy the per-GPU context.  `device` = HIP device ordinal (the rank's local GPU).
+ * Replaces nothing in the reference (its recursion type owns host arrays only, recursion.f90:41-116,
+ * allocated in restore_to_default :3713-3790); the drop-in module creates the context lazily on the
+ * first recur* call (finalizer trap: SURVEY.md section 8b). */
+int rsrec_create(rsrec_t **out, int device);
+int rsrec_destroy(rsrec_t *h);
+
+/* Geometry tables read by the recursion: lattice%kk, %nn, %iz, %nmax, %ntype
+ * (lattice.f90:138-239; read at recursion.f90:1577-1580, :1603-1606).
+ *   nn  : int32 (kk, nncols) column-major; nn(i,1) = number of slots incl. on-site, nn(i,j>=2) = atom or 0
+ *   iz  : int32 (kk) atom type, 1..ntype
+ *   nmax: the first nmax atoms carry per-atom blocks `hall` (impurity region), 0 for bulk/surface */
+int rsrec_set_lattice(rsrec_t *h, int kk, int nncols, const int32_t *nn, const int32_t *iz, int nmax, int ntype);
+
+/* Operator blocks read by the recursion: hamiltonian%ee, %lsham, %eeo, %enim, %hall, %hallo
+ * (hamiltonian.f90:51-64, shapes :290-301).  Must be called again whenever the caller rebuilt them
+ * (self.f90:777-797 rebuilds before every recur* call).
+ *   ee, eeo    : complex (18,18,nslots,ntype)      hall, hallo : complex (18,18,nslots,nmax) (NULL if nmax = 0)
+ *   lsham, enim: complex (18,18,ntype)
+ *   hoh != 0 selects H = h - h*o*h + e_nu + l.s (hop_b_hoh, recursion.f90:1411); eeo/enim/hallo may be NULL otherwise.
+ *   nsp: control%nsp (1..4); only the scalar recursion reads it (hop is a no-op unless nsp = 1, recursion.f90:3326). */
+int rsrec_set_hamiltonian(rsrec_t *h, int nslots, int hoh, int nsp, const double *ee, const double *lsham,
+                          const double *eeo, const double *enim, const double *hall, const double *hallo);
+
+/* Block Lanczos recursion for `nsites` independent chains seeded with psi(:,:,seed) = I18.
+ * Replaces recur_b (recursion.f90:1807-1866) + crecal_b (:1873-1973) + hop_b/hop_b_hoh (:1560/:1411).
+ *   seed_atoms : int32 (nsites), 1-based cluster atom numbers (lattice%irec(start_atom:end_atom))
+ *   a_b, b2_b  : complex (18,18,lld,nsites) out; a_b(:,:,lld,:) = 0 and b2_b(:,:,1,:) = I as in :1836-1837.
+ * b2_b holds B^2 (NOT its square root: the reference takes the root later in zsqr). */
+int rsrec_block_lanczos(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, double *a_b, double *b2_b);
+
+/* Same with general seeds: chain c starts from sum_k coef(k,c) * I18 placed on atom seed(k,c), k = 1..nseed.
+ * Replaces the four-chain seeds of recur_b_ij (recursion.f90:1655-1800: (psi_i +- psi_j)/sqrt2, (psi_i +- i psi_j)/sqrt2).
+ *   seed_atoms : int32 (nseed, nchains);  seed_coef : complex (nseed, nchains) */
+int rsrec_block_lanczos_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
+                               int lld, double *a_b, double *b2_b);
+
+/* In-place principal square root of `nmat` Hermitian 18x18 matrices: b2_b <- sqrt(b2_b).
+ * Replaces zsqr (recursion.f90:1980-2023). */
+int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);
+
+/* Chebyshev (KPM, moment doubling) recursion.  Replaces chebyshev_recur (recursion.f90:3057-3130) with
+ * cheb_0th_mom (:2145), cheb_1st_mom[_hoh] (:2169/:2245), chebyshev_recur_ll[_hoh] (:2495/:2605).
+ *   a, b : scale and shift, a = (energy_max-energy_min)/(2-0.3), b = (energy_max+energy_min)/2 (:3078-3079)
+ *   mu_n : complex (18,18,2*lld+2,nsites) out
+ * Returns RSREC_ERR_DIVERGED if sum(real(mu_n(:,:,2ll+2))) > 1000 at any step (:2594). */
+int rsrec_chebyshev(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, double a, double b, double *mu_n);
+
+/* Scalar Haydock recursion, one chain per (site, orbital).  Replaces recur (recursion.f90:3485-3532),
+ * crecal (:3423-3478), hop (:3310-3416).
+ *   a, b2 : real (llmax,18,nsites) out (the (:,:,:,1) plane of the reference's a/b2); rows > lld are zeroed. */
+int rsrec_scalar_lanczos(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, int llmax, double *a, double *b2);
+
+/* Site partition of get_mpi_variables (mpi.f90:32-58): 1-based inclusive range owned by `rank`. */
+void rsrec_site_partition(int rank, int nprocs, int nsites, int *start_atom, int *end_atom);
+
+/* Last error text of this handle (NUL-terminated, truncated to n). */
+int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
+
+/* ---- tuning / measurement (not part of the reference interface) ---- */
+/* key/value knobs: "batch" (chains advanced together, 0 = auto), "kernels" (0 = auto, 1 = VALU reference kernels, 2 = MFMA) */
+int rsrec_set_option(rsrec_t *h, const char *key, long value);
+/* Timing of the last recursion call, measured with HIP events on the engine's own stream:
+ *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,
+ *   out[3] atom-steps processed (sum over chains and steps of active atoms), out[4] block multiplies in H|psi>,
+ *   out[5] ms in the remaining recursion kernels, out[6] host ms (region bookkeeping + transfers) */
+int rsrec_get_timing(rsrec_t *h, double *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSREC_H */

@@ -1,0 +1,717 @@
+// librsrec: C ABI (include/rsrec.h) + host orchestration of the MI355X recursion engine.
+//
+// Reference path replaced: source/recursion.f90 of rslmtoasa/rslmtoasa -- recur_b/crecal_b/hop_b/hop_b_hoh
+// (:1807/:1873/:1560/:1411), chebyshev_recur & helpers (:3057, :2145-2763), recur/crecal/hop (:3485/:3423/:3310),
+// zsqr (:1980).  Everything numerical runs in hand-written HIP kernels for gfx950; there is no CPU fallback.
+//
+// Engine design:
+//  * all chains of a call are independent (one per recursion site); they are advanced TOGETHER in batches so that
+//    the small active regions of the first steps still fill the 256 CUs;
+//  * the region growth of the reference (izero/idum/irlist) is purely topological: a breadth-first search from the
+//    seed on the host gives the atom order; "active after L applications of H" = a prefix of that order;
+//  * work vectors (psi, pmn, ...) never leave HBM; only the 18x18 coefficients come back to the host;
+//  * reductions are two-stage and fixed-order (no float atomics) so results are run-to-run reproducible.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rsrec.h"
+#include "kernels_valu.hpp"
+#include "kernels_mfma.hpp"
+
+using namespace rsrec;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct rsrec_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // lattice (host copies for the region search + device tables)
+    bool have_lattice = false, have_ham = false;
+    int kk = 0, nslots = 0, nmax = 0, ntype = 0;
+    std::vector<int> nbr;        // [kk][nslots] 0-based, -1 absent, slot 0 = self
+    std::vector<int> iz0;        // 0-based types
+    std::vector<int> radj_ptr, radj;  // reverse adjacency: atoms whose neighbour list contains n
+    DevBuf d_nbr, d_iz;
+    // hamiltonian
+    int hslots = 0, hoh = 0, nsp = 2;
+    DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
+    MfmaOperator mfma_op;
+    // work
+    DevBuf d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
+    // options
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0;
+    // timing of last call
+    double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
+    double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(rsrec_t* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCK(h, call)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) return fail(h, RSREC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+hipEvent_t next_event(rsrec_t* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    hipEvent_t e = h->ev_pool[h->ev_used++];
+    (void)hipEventRecord(e, h->stream);
+    return e;
+}
+
+struct Region {
+    std::vector<int> order;   // atoms sorted by (distance, index)
+    std::vector<int> cum;     // cum[L] = #atoms with distance <= L, L = 0..nlev-1
+};
+
+// Breadth-first growth of the active region, restating izero/idum of hop_b (recursion.f90:1604-1636):
+// atom i joins the region when one of ITS neighbour slots holds an atom already in it.
+void grow_region(const rsrec_t* h, const int* seeds, int nseed, int nlev, Region& R) {
+    const int kk = h->kk;
+    std::vector<int> dist(kk, -1);
+    R.order.clear();
+    R.order.reserve(kk);
+    R.cum.assign(nlev, 0);
+    std::vector<int> frontier, next;
+    for (int s = 0; s < nseed; ++s)
+        if (dist[seeds[s]] < 0) { dist[seeds[s]] = 0; frontier.push_back(seeds[s]); }
+    std::sort(frontier.begin(), frontier.end());
+    int level = 0;
+    while (!frontier.empty() && level < nlev) {
+        R.order.insert(R.order.end(), frontier.begin(), frontier.end());
+        R.cum[level] = (int)R.order.size();
+        next.clear();
+        for (int n : frontier)
+            for (int q = h->radj_ptr[n]; q < h->radj_ptr[n + 1]; ++q) {
+                const int i = h->radj[q];
+                if (dist[i] < 0) { dist[i] = level + 1; next.push_back(i); }
+            }
+        std::sort(next.begin(), next.end());
+        frontier.swap(next);
+        ++level;
+    }
+    for (int L = std::max(level, 1); L < nlev; ++L) R.cum[L] = R.cum[L - 1];
+    R.order.resize(kk, 0);   // tail is never read (cum bounds every loop)
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rsrec_version(void) { return 100; }
+
+extern "C" int rsrec_create(rsrec_t** out, int device) {
+    if (!out) return RSREC_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RSREC_ERR_DEVICE;   // no CPU fallback by design
+    if (device < 0 || device >= ndev) return RSREC_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return RSREC_ERR_DEVICE;
+    rsrec_t* h = new rsrec_handle();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RSREC_ERR_DEVICE; }
+    *out = h;
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_destroy(rsrec_t* h) {
+    if (!h) return RSREC_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    DevBuf* all[] = {&h->d_nbr, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+                     &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
+                     &h->d_status, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
+    for (auto b : all) b->release();
+    h->mfma_op.release();
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_last_error(rsrec_t* h, char* buf, size_t n) {
+    if (!h || !buf || n == 0) return RSREC_ERR_ARG;
+    snprintf(buf, n, "%s", h->err.c_str());
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
+    if (!h || !key) return RSREC_ERR_ARG;
+    if (!strcmp(key, "batch")) h->opt_batch = value;
+    else if (!strcmp(key, "kernels")) h->opt_kernels = value;
+    else if (!strcmp(key, "nblk")) h->opt_nblk = value;
+    else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
+    if (!h || !out) return RSREC_ERR_ARG;
+    const double v[7] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms};
+    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+    return RSREC_OK;
+}
+
+extern "C" void rsrec_site_partition(int rank, int nprocs, int nsites, int* start_atom, int* end_atom) {
+    // get_mpi_variables, mpi.f90:37-46
+    int per = nsites / nprocs;
+    const int rem = nsites % nprocs;
+    int start;
+    if (rank < rem) { per += 1; start = rank * per + 1; }
+    else start = rank * per + rem + 1;
+    *start_atom = start;
+    *end_atom = start + per - 1;
+}
+
+extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* nn, const int32_t* iz, int nmax, int ntype) {
+    if (!h || !nn || !iz || kk <= 0 || nncols < 1 || nmax < 0 || nmax > kk || ntype < 1) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: bad argument");
+    HIPCK(h, hipSetDevice(h->device));
+    int nslots = 1;
+    for (int i = 0; i < kk; ++i) {
+        const int nr = nn[i];
+        if (nr < 0 || nr > nncols) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: nn(%d,1)=%d outside 0..%d", i + 1, nr, nncols);
+        nslots = std::max(nslots, nr);
+        if (iz[i] < 1 || iz[i] > ntype) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: iz(%d)=%d outside 1..%d", i + 1, iz[i], ntype);
+    }
+    h->kk = kk; h->nslots = nslots; h->nmax = nmax; h->ntype = ntype;
+    h->nbr.assign((size_t)kk * nslots, -1);
+    h->iz0.resize(kk);
+    std::vector<int> deg(kk + 1, 0);
+    for (int i = 0; i < kk; ++i) {
+        h->iz0[i] = iz[i] - 1;
+        h->nbr[(size_t)i * nslots] = i;
+        const int nr = nn[i];
+        for (int j = 1; j < nr; ++j) {   // slots 2..nn(i,1) of the reference (recursion.f90:1614)
+            const int n = nn[(size_t)i + (size_t)kk * j];
+            if (n == 0) continue;
+            if (n < 0 || n > kk) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: nn(%d,%d)=%d outside 0..%d", i + 1, j + 1, n, kk);
+            h->nbr[(size_t)i * nslots + j] = n - 1;
+            deg[n - 1]++;
+        }
+    }
+    h->radj_ptr.assign(kk + 1, 0);
+    for (int n = 0; n < kk; ++n) h->radj_ptr[n + 1] = h->radj_ptr[n] + deg[n];
+    h->radj.resize(h->radj_ptr[kk]);
+    std::vector<int> fill(h->radj_ptr.begin(), h->radj_ptr.end() - 1);
+    for (int i = 0; i < kk; ++i)
+        for (int j = 1; j < nslots; ++j) {
+            const int n = h->nbr[(size_t)i * nslots + j];
+            if (n >= 0) h->radj[fill[n]++] = i;
+        }
+    HIPCK(h, h->d_nbr.reserve(h->nbr.size() * sizeof(int)));
+    HIPCK(h, h->d_iz.reserve((size_t)kk * sizeof(int)));
+    HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
+    h->have_lattice = true;
+    h->have_ham = false;   // operator tables depend on nmax/ntype: must be set again
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, const double* ee, const double* lsham, const double* eeo,
+                                     const double* enim, const double* hall, const double* hallo) {
+    if (!h) return RSREC_ERR_ARG;
+    if (!h->have_lattice) return fail(h, RSREC_ERR_ARG, "rsrec_set_hamiltonian: call rsrec_set_lattice first");
+    if (!ee || !lsham || nslots < h->nslots) return fail(h, RSREC_ERR_ARG, "rsrec_set_hamiltonian: ee/lsham missing or nslots=%d < lattice slots %d", nslots, h->nslots);
+    if (hoh && (!eeo || !enim)) return fail(h, RSREC_ERR_ARG, "rsrec_set_hamiltonian: hoh requires eeo and enim");
+    if (h->nmax > 0 && (!hall || (hoh && !hallo))) return fail(h, RSREC_ERR_ARG, "rsrec_set_hamiltonian: nmax>0 requires hall (and hallo with hoh)");
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t B = 2 * (size_t)BLK;   // doubles per block
+    const int ntype = h->ntype, nmax = h->nmax;
+    h->hslots = nslots; h->hoh = hoh ? 1 : 0; h->nsp = nsp;
+    // stencil with the on-site spin-orbit block folded into slot 0 (locham = ee(:,:,1,ih) + lsham(:,:,ih), recursion.f90:1608)
+    std::vector<double> st(ee, ee + B * nslots * ntype);
+    if (!hoh)
+        for (int t = 0; t < ntype; ++t)
+            for (size_t e = 0; e < B; ++e) st[B * nslots * t + e] += lsham[B * t + e];
+    HIPCK(h, h->d_hst.reserve(st.size() * 8));
+    HIPCK(h, hipMemcpy(h->d_hst.p, st.data(), st.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double> loc;
+    if (nmax > 0) {
+        loc.assign(hall, hall + B * nslots * nmax);
+        if (!hoh)
+            for (int i = 0; i < nmax; ++i)
+                for (size_t e = 0; e < B; ++e) loc[B * nslots * i + e] += lsham[B * h->iz0[i] + e];   // :1582
+        HIPCK(h, h->d_hloc.reserve(loc.size() * 8));
+        HIPCK(h, hipMemcpy(h->d_hloc.p, loc.data(), loc.size() * 8, hipMemcpyHostToDevice));
+    }
+    HIPCK(h, h->d_lsham.reserve(B * ntype * 8));
+    HIPCK(h, hipMemcpy(h->d_lsham.p, lsham, B * ntype * 8, hipMemcpyHostToDevice));
+    if (hoh) {
+        HIPCK(h, h->d_host.reserve(B * nslots * ntype * 8));
+        HIPCK(h, hipMemcpy(h->d_host.p, eeo, B * nslots * ntype * 8, hipMemcpyHostToDevice));
+        HIPCK(h, h->d_enim.reserve(B * ntype * 8));
+        HIPCK(h, hipMemcpy(h->d_enim.p, enim, B * ntype * 8, hipMemcpyHostToDevice));
+        if (nmax > 0) {
+            HIPCK(h, h->d_holoc.reserve(B * nslots * nmax * 8));
+            HIPCK(h, hipMemcpy(h->d_holoc.p, hallo, B * nslots * nmax * 8, hipMemcpyHostToDevice));
+        }
+    }
+    // MFMA-fragment form of the same operator tables
+    {
+        const char* msg = h->mfma_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
+                                           (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham);
+        if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
+    }
+    h->have_ham = true;
+    return RSREC_OK;
+}
+
+namespace {
+
+DevProblem make_problem(const rsrec_t* h) {
+    DevProblem P;
+    P.kk = h->kk; P.nslots = h->nslots; P.hstride = h->hslots; P.nmax = h->nmax; P.hoh = h->hoh;
+    P.nbr = h->d_nbr.as<int>(); P.iz = h->d_iz.as<int>();
+    P.h_st = h->d_hst.as<double2>(); P.h_loc = h->d_hloc.as<double2>();
+    P.ho_st = h->d_host.as<double2>(); P.ho_loc = h->d_holoc.as<double2>();
+    P.enim = h->d_enim.as<double2>(); P.lsham = h->d_lsham.as<double2>();
+    return P;
+}
+
+struct BatchPlan {
+    int batch = 1, nblk = 1;
+};
+
+// how many chains are advanced together, and how many workgroups each gets
+int plan_batch(rsrec_t* h, int nchains, int nvec, size_t vec_elems_per_chain, BatchPlan& bp) {
+    size_t free_b = 0, total_b = 0;
+    HIPCK(h, hipMemGetInfo(&free_b, &total_b));
+    size_t reusable = 0;
+    for (int v = 0; v < 5; ++v) reusable += h->d_vec[v].bytes;
+    const double per_chain = (double)nvec * vec_elems_per_chain * sizeof(double2) + (double)h->kk * 4 + 4096;
+    long cap = (long)((0.85 * (double)(free_b + reusable)) / per_chain);
+    if (cap < 1) return fail(h, RSREC_ERR_DEVICE, "not enough device memory for one chain (%.1f MB needed, %.1f MB free)", per_chain / 1e6, free_b / 1e6);
+    long b = h->opt_batch > 0 ? h->opt_batch : 64;
+    b = std::min<long>(b, cap);
+    b = std::min<long>(b, nchains);
+    bp.batch = (int)std::max<long>(b, 1);
+    long nblk = h->opt_nblk > 0 ? h->opt_nblk : std::max<long>(2048 / bp.batch, 16);
+    nblk = std::min<long>(nblk, 256);
+    nblk = std::min<long>(nblk, (h->kk + TILE_ATOMS - 1) / TILE_ATOMS);
+    bp.nblk = (int)std::max<long>(nblk, 1);
+    return RSREC_OK;
+}
+
+// Upload the regions of one batch. seeds: [nb][nseed] 0-based.
+int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, int napply, bool two_pass, double& atom_steps, double& block_mults) {
+    const int kk = h->kk;
+    std::vector<int> order((size_t)nb * kk), cum((size_t)nb * nlev);
+    std::vector<double> as(nb, 0.0), bm(nb, 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < nb; ++c) {
+        Region R;
+        grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, R);
+        std::copy(R.order.begin(), R.order.end(), order.begin() + (size_t)c * kk);
+        std::copy(R.cum.begin(), R.cum.end(), cum.begin() + (size_t)c * nlev);
+        // bookkeeping in the reference's terms: application t (1..napply) multiplies one block per (atom, slot) whose
+        // source atom lies in the region before it; post-hop work runs on the region after it.
+        double a_s = 0.0, b_m = 0.0;
+        for (int t = 1; t <= napply; ++t) {
+            const int lv_after = two_pass ? 2 * t : t;
+            a_s += R.cum[std::min(lv_after, nlev - 1)];
+            if (two_pass) b_m += 2.0 * R.cum[2 * (t - 1)];   // enim*psi and lsham*psi on-site products (hop_b_hoh :1437-1438)
+        }
+        // count products: for each atom n at distance d, it is a source in applications with region-before containing it
+        // region before application t = level (t-1) [one pass] ; two passes: pass1 before-level 2(t-1), pass2 before-level 2t-1
+        std::vector<int> lev_of(kk, -1);
+        {
+            int lv = 0;
+            for (int q = 0; q < R.cum[nlev - 1]; ++q) {
+                while (q >= R.cum[lv]) ++lv;
+                lev_of[R.order[q]] = lv;
+            }
+        }
+        std::vector<double> uses(nlev + 1, 0.0);   // uses[d] = number of applications in which a source at distance d is active
+        for (int d = 0; d < nlev; ++d) {
+            double u = 0.0;
+            for (int t = 1; t <= napply; ++t) {
+                if (!two_pass) { if (d <= t - 1) u += 1.0; }
+                else { if (d <= 2 * (t - 1)) u += 1.0; if (d <= 2 * t - 1) u += 1.0; }
+            }
+            uses[d] = u;
+        }
+        for (int n = 0; n < kk; ++n) {
+            if (lev_of[n] < 0) continue;
+            const int fan = 1 + (h->radj_ptr[n + 1] - h->radj_ptr[n]);   // on-site + every atom that lists n as a neighbour
+            b_m += uses[lev_of[n]] * fan;
+        }
+        as[c] = a_s; bm[c] = b_m;
+    }
+    for (int c = 0; c < nb; ++c) { atom_steps += as[c]; block_mults += bm[c]; }
+    HIPCK(h, h->d_order.reserve(order.size() * 4));
+    HIPCK(h, h->d_cum.reserve(cum.size() * 4));
+    HIPCK(h, hipMemcpyAsync(h->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->d_cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
+    return RSREC_OK;
+}
+
+void reset_timing(rsrec_t* h) {
+    h->t_total_ms = h->t_hop_ms = h->t_rest_ms = h->t_host_ms = 0;
+    h->n_hop_launch = h->n_atom_steps = h->n_block_mult = 0;
+    h->ev_used = 0;
+}
+
+double ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (!a || !b || hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0;
+    return ms;
+}
+
+int check_ready(rsrec_t* h, const char* who) {
+    if (!h) return RSREC_ERR_ARG;
+    if (!h->have_lattice || !h->have_ham) return fail(h, RSREC_ERR_ARG, "%s: lattice and hamiltonian must be set first", who);
+    return RSREC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld,
+                                          double* a_b, double* b2_b) {
+    int rc = check_ready(h, "rsrec_block_lanczos");
+    if (rc) return rc;
+    if (nchains < 0 || nseed < 1 || lld < 1 || !a_b || !b2_b || (nchains > 0 && !seed_atoms)) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: bad argument");
+    for (int q = 0; q < nchains * nseed; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nchains == 0) return RSREC_OK;
+    const int kk = h->kk;
+    const bool hoh = h->hoh != 0;
+    const bool use_mfma = (h->opt_kernels == 2);
+    const int nsteps = lld - 1;
+    const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
+    const size_t velems = (size_t)kk * BLK;                 // double2 per chain per vector
+    const int nvec = hoh ? 3 : 2;
+    BatchPlan bp;
+    rc = plan_batch(h, nchains, nvec, velems, bp);
+    if (rc) return rc;
+    const int B = bp.batch, nblk = bp.nblk;
+    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double2)));
+    HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
+    HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
+    HIPCK(h, h->d_bmats.reserve((size_t)B * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_status.reserve(64));
+    HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
+    HIPCK(h, h->d_seedcoef.reserve((size_t)B * nseed * sizeof(double2)));
+    HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
+    double2* psi = h->d_vec[0].as<double2>();
+    double2* pmn = h->d_vec[1].as<double2>();
+    double2* hpsi = h->d_vec[2].as<double2>();
+    double2* dA = h->d_coefA.as<double2>();
+    double2* dB = h->d_coefB.as<double2>();
+    const DevProblem P = make_problem(h);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_orth), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ATOMS * BLK * (int)sizeof(double2)));
+        attr_set = true;
+    }
+    const size_t cstride = (size_t)lld * BLK;
+    hipEvent_t ev_begin = next_event(h);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
+
+    for (int c0 = 0; c0 < nchains; c0 += B) {
+        const int nb = std::min(B, nchains - c0);
+        const auto th0 = std::chrono::steady_clock::now();
+        std::vector<int> seeds0((size_t)nb * nseed);
+        std::vector<double> coef((size_t)nb * nseed * 2);
+        for (int q = 0; q < nb * nseed; ++q) {
+            seeds0[q] = seed_atoms[(size_t)c0 * nseed + q] - 1;
+            coef[2 * q] = seed_coef ? seed_coef[2 * ((size_t)c0 * nseed + q)] : 1.0;
+            coef[2 * q + 1] = seed_coef ? seed_coef[2 * ((size_t)c0 * nseed + q) + 1] : 0.0;
+        }
+        rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, nsteps, hoh, h->n_atom_steps, h->n_block_mult);
+        if (rc) return rc;
+        HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+
+        ChainView CV;
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.kk = kk;
+        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double2), h->stream));
+        HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
+        HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
+        k_seed<<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
+        const dim3 grid(nblk, nb);
+        for (int ll = 0; ll < nsteps; ++ll) {
+            const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
+            hipEvent_t e0 = next_event(h);
+            ApplyArgs G{};
+            G.partial = h->d_partial.as<double2>();
+            if (!hoh) {
+                G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                if (use_mfma) launch_hop_mfma(h->mfma_op, P, CV, G, grid, h->stream);
+                else k_apply<AM_LANCZOS><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+            } else {
+                G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
+                k_apply<AM_STORE><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                G.in = hpsi; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                k_apply<AM_HOH_LANCZOS><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+            }
+            k_reduce_a<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dA + (size_t)ll * BLK, cstride);
+            hipEvent_t e1 = next_event(h);
+            hop_ev.emplace_back(e0, e1);
+            h->n_hop_launch += hoh ? 2 : 1;
+            k_orth<<<grid, NTHREADS, TILE_ATOMS * BLK * sizeof(double2), h->stream>>>(kk, CV, lv_final, psi, pmn, dA + (size_t)ll * BLK, cstride, h->d_partial.as<double2>());
+            k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
+            k_update<<<grid, NTHREADS, 0, h->stream>>>(kk, CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
+        }
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipMemcpyAsync(a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipMemcpyAsync(b2_b + (size_t)c0 * cstride * 2, dB, (size_t)nb * cstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    hipEvent_t ev_end = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(ev_begin, ev_end);
+    for (auto& pr : hop_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);
+    h->t_rest_ms = h->t_total_ms - h->t_hop_ms;
+    int status = 0;
+    HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
+    if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_block_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double* a_b, double* b2_b) {
+    return rsrec_block_lanczos_seeded(h, nsites, 1, seed_atoms, nullptr, lld, a_b, b2_b);
+}
+
+extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
+    if (!h || nmat < 0 || (nmat > 0 && !b2_b)) return fail(h, RSREC_ERR_ARG, "rsrec_zsqr: bad argument");
+    if (nmat == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)nmat * BLK * sizeof(double2);
+    HIPCK(h, h->d_mu.reserve(bytes));
+    HIPCK(h, h->d_status.reserve(64));
+    HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->d_mu.p, b2_b, bytes, hipMemcpyHostToDevice, h->stream));
+    k_zsqr<<<nmat, 256, 0, h->stream>>>(h->d_mu.as<double2>(), h->d_status.as<int>());
+    HIPCK(h, hipGetLastError());
+    HIPCK(h, hipMemcpyAsync(b2_b, h->d_mu.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    int status = 0;
+    HIPCK(h, hipMemcpyAsync(&status, h->d_status.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+    int rc = check_ready(h, "rsrec_chebyshev");
+    if (rc) return rc;
+    if (nsites < 0 || lld < 1 || !mu_n || (nsites > 0 && !seed_atoms) || a == 0.0) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: bad argument");
+    for (int q = 0; q < nsites; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nsites == 0) return RSREC_OK;
+    const int kk = h->kk;
+    const bool hoh = h->hoh != 0;
+    const int napply = lld + 1;                                  // first moment + lld steps
+    const int nlev = (hoh ? 2 * napply : napply) + 1;
+    const int nmom = 2 * lld + 2;
+    const size_t velems = (size_t)kk * BLK;
+    const int nvec = hoh ? 4 : 3;
+    BatchPlan bp;
+    rc = plan_batch(h, nsites, nvec, velems, bp);
+    if (rc) return rc;
+    const int B = bp.batch, nblk = bp.nblk;
+    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double2)));
+    HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
+    HIPCK(h, h->d_status.reserve(64));
+    HIPCK(h, h->d_seed.reserve((size_t)B * 4));
+    HIPCK(h, h->d_seedcoef.reserve((size_t)B * sizeof(double2)));
+    HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
+    const DevProblem P = make_problem(h);
+    const size_t mstride = (size_t)nmom * BLK;
+    double2* mu = h->d_mu.as<double2>();
+    hipEvent_t ev_begin = next_event(h);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
+    for (int c0 = 0; c0 < nsites; c0 += B) {
+        const int nb = std::min(B, nsites - c0);
+        const auto th0 = std::chrono::steady_clock::now();
+        std::vector<int> seeds0(nb);
+        std::vector<double> coef((size_t)nb * 2);
+        for (int q = 0; q < nb; ++q) { seeds0[q] = seed_atoms[c0 + q] - 1; coef[2 * q] = 1.0; coef[2 * q + 1] = 0.0; }
+        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, h->n_atom_steps, h->n_block_mult);
+        if (rc) return rc;
+        HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+        ChainView CV;
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.kk = kk;
+        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double2), h->stream));
+        HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
+        double2* p0 = h->d_vec[0].as<double2>();
+        double2* p1 = h->d_vec[1].as<double2>();
+        double2* p2 = h->d_vec[2].as<double2>();
+        double2* tmp = h->d_vec[3].as<double2>();
+        k_seed<<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
+        k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride);                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
+        const dim3 grid(nblk, nb);
+        for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
+            const bool first = (t == 1);
+            const int lv_final = hoh ? 2 * t : t;
+            hipEvent_t e0 = next_event(h);
+            ApplyArgs G{};
+            G.partial = h->d_partial.as<double2>();
+            G.a = a; G.b = b;
+            double2* src = first ? p0 : p1;
+            double2* dst = first ? p1 : p2;
+            if (!hoh) {
+                G.in = src; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
+                if (first) k_apply<AM_CHEB1><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_CHEBN><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+            } else {
+                G.in = src; G.out = tmp; G.level = 2 * t - 1;
+                k_apply<AM_STORE><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                G.in = tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
+                if (first) k_apply<AM_HOH_CHEB1><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_HOH_CHEBN><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+            }
+            k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>());
+            hipEvent_t e1 = next_event(h);
+            hop_ev.emplace_back(e0, e1);
+            h->n_hop_launch += hoh ? 2 : 1;
+            if (!first) { double2* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
+        }
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipMemcpyAsync(mu_n + (size_t)c0 * mstride * 2, mu, (size_t)nb * mstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    hipEvent_t ev_end = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(ev_begin, ev_end);
+    for (auto& pr : hop_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);
+    h->t_rest_ms = h->t_total_ms - h->t_hop_ms;
+    int status = 0;
+    HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
+    if (status & 2) return fail(h, RSREC_ERR_DIVERGED, "Chebyshev moments did not converge. Check energy limits energy_min and energy_max");
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, int llmax, double* a, double* b2) {
+    int rc = check_ready(h, "rsrec_scalar_lanczos");
+    if (rc) return rc;
+    if (nsites < 0 || lld < 1 || llmax < lld || !a || !b2 || (nsites > 0 && !seed_atoms)) return fail(h, RSREC_ERR_ARG, "rsrec_scalar_lanczos: bad argument");
+    for (int q = 0; q < nsites; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_scalar_lanczos: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    std::fill(a, a + (size_t)llmax * NB * nsites, 0.0);
+    std::fill(b2, b2 + (size_t)llmax * NB * nsites, 0.0);
+    if (nsites == 0) return RSREC_OK;
+    if (h->nsp != 1) {
+        // hop() is a no-op unless nsp = 1 (recursion.f90:3326-3415): a stays 0 and crecal (:3466) divides by sqrt(0),
+        // so the reference returns b2 = (1, 0, 0, NaN, NaN, ...).  Mirrored, not "fixed".
+        for (size_t q = 0; q < (size_t)NB * nsites; ++q) {
+            b2[q * llmax] = 1.0;
+            for (int ll = 3; ll < lld; ++ll) b2[q * llmax + ll] = std::nan("");
+        }
+        return RSREC_OK;
+    }
+    const int kk = h->kk;
+    const int nsteps = lld - 1;
+    const int nlev = nsteps + 1;
+    const size_t velems = (size_t)kk * NB;
+    const int B = (int)std::min<long>(nsites, h->opt_batch > 0 ? h->opt_batch : 16);
+    const int nblk = (int)std::min<long>(std::max<long>(1, (kk + TILE_ATOMS - 1) / TILE_ATOMS), 64);
+    const int nch = B * NB;
+    for (int v = 0; v < 2; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)nch * velems * sizeof(double2)));
+    HIPCK(h, h->d_scal.reserve((size_t)nch * (nblk + 2 * (size_t)lld) * sizeof(double) + 64));
+    HIPCK(h, h->d_seed.reserve((size_t)nch * 2 * 4));
+    double2* psi = h->d_vec[0].as<double2>();
+    double2* pmn = h->d_vec[1].as<double2>();
+    double* part = h->d_scal.as<double>();
+    double* ca = part + (size_t)nch * nblk;
+    double* cb = ca + (size_t)nch * lld;
+    const DevProblem P = make_problem(h);
+    hipEvent_t ev_begin = next_event(h);
+    std::vector<double> ha((size_t)nch * lld), hb((size_t)nch * lld);
+    for (int c0 = 0; c0 < nsites; c0 += B) {
+        const int nb = std::min(B, nsites - c0);
+        const int nc = nb * NB;
+        std::vector<int> seeds0(nb), so((size_t)nc * 2);
+        for (int q = 0; q < nb; ++q) {
+            seeds0[q] = seed_atoms[c0 + q] - 1;
+            for (int l = 0; l < NB; ++l) { so[2 * (q * NB + l)] = seeds0[q]; so[2 * (q * NB + l) + 1] = l; }
+        }
+        double dummy1 = 0, dummy2 = 0;
+        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, nsteps, false, dummy1, dummy2);
+        if (rc) return rc;
+        h->n_atom_steps += dummy1 * NB;
+        HIPCK(h, hipMemcpyAsync(h->d_seed.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        ChainView CV;
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.kk = kk;
+        for (int v = 0; v < 2; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nc * velems * sizeof(double2), h->stream));
+        HIPCK(h, hipMemsetAsync(ca, 0, (size_t)nch * 2 * lld * sizeof(double), h->stream));
+        k_scalar_seed<<<nc, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), cb, lld);
+        const dim3 grid(nblk, nc);
+        for (int ll = 0; ll < nsteps; ++ll) {
+            k_scalar_hop<<<grid, NTHREADS, 0, h->stream>>>(P, CV, ll + 1, psi, pmn, part);
+            k_scalar_reduce<<<nc, 64, 0, h->stream>>>(part, nblk, ca, lld, ll);
+            k_scalar_orth<<<grid, NTHREADS, 0, h->stream>>>(kk, CV, ll + 1, psi, pmn, ca, lld, ll, part);
+            k_scalar_reduce<<<nc, 64, 0, h->stream>>>(part, nblk, cb, lld, ll + 1);
+            k_scalar_update<<<grid, NTHREADS, 0, h->stream>>>(kk, CV, ll + 1, psi, pmn, cb, lld, ll);
+            h->n_hop_launch += 1;
+        }
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipMemcpyAsync(ha.data(), ca, (size_t)nc * lld * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipMemcpyAsync(hb.data(), cb, (size_t)nc * lld * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        for (int q = 0; q < nc; ++q)
+            for (int ll = 0; ll < lld; ++ll) {
+                a[(size_t)llmax * ((size_t)c0 * NB + q) + ll] = ha[(size_t)q * lld + ll];
+                b2[(size_t)llmax * ((size_t)c0 * NB + q) + ll] = hb[(size_t)q * lld + ll];
+            }
+    }
+    hipEvent_t ev_end = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(ev_begin, ev_end);
+    return RSREC_OK;
+}

@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's ``recursion_mod`` (source/recursion.f90) on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the Fortran type the rest of RS-LMTO-ASA drives
+(recursion.f90:41-116): a ``Recursion`` object borrows ``hamiltonian``/``lattice``/``control``/``energy``
+objects, exposes ``recur()``, ``recur_b()``, ``chebyshev_recur()``, ``recur_b_ij()``, ``zsqr()`` and fills
+``a, b2, a_b, b2_b, mu_n`` with the reference's shapes and index order (arrays are Fortran-ordered numpy
+arrays, so ``a_b[l, m, ll, site]`` reads like ``a_b(l+1, m+1, ll+1, site+1)``).
+
+All arithmetic happens in librsrec (HIP kernels); this module only marshals arrays.  The production host
+for the reference is the Fortran shim under ``fortran/`` -- this Python mirror exists so the parity tests
+and the benchmark read like the reference's own call sites (self.f90:799-806, :829).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class Control:
+    """control%lld, %llsp, %nsp, %recur (control.f90:36-164)."""
+    lld: int = 21
+    llsp: int = 0
+    nsp: int = 2
+    recur: str = "block"
+
+
+@dataclass
+class Energy:
+    """energy%energy_min / %energy_max (energy.f90:175-207)."""
+    energy_min: float = -1.0
+    energy_max: float = 1.0
+
+
+@dataclass
+class Lattice:
+    """The tables of lattice.f90:138-239 the recursion reads."""
+    nn: np.ndarray            # (kk, nncols) int32, 1-based, 0 = absent, column 0 = count
+    iz: np.ndarray            # (kk,) int32 1-based type
+    irec: np.ndarray          # (nrec,) int32 1-based recursion sites
+    nmax: int = 0
+    ntype: int = 1
+    ijpair: np.ndarray = None  # (njij, 2) atom pairs for recur_b_ij (lattice%ijpair)
+
+    @property
+    def kk(self):
+        return self.nn.shape[0]
+
+    @property
+    def nrec(self):
+        return len(self.irec)
+
+
+@dataclass
+class Hamiltonian:
+    """hamiltonian%ee, %lsham, %eeo, %enim, %hall, %hallo, %hoh (hamiltonian.f90:51-70)."""
+    ee: np.ndarray
+    lsham: np.ndarray
+    eeo: np.ndarray = None
+    enim: np.ndarray = None
+    hall: np.ndarray = None
+    hallo: np.ndarray = None
+    hoh: bool = False
+    local_axis: bool = False
+
+
+def site_partition(rank, nprocs, nsites):
+    """get_mpi_variables (mpi.f90:32-58): 1-based inclusive (start_atom, end_atom)."""
+    s, e = C.c_int(), C.c_int()
+    _lib.lib().rsrec_site_partition(rank, nprocs, nsites, C.byref(s), C.byref(e))
+    return s.value, e.value
+
+
+def chebyshev_scaling(energy_min, energy_max):
+    """a, b of chebyshev_recur (recursion.f90:3078-3079).  The literal 0.3 there is default REAL(4)."""
+    a = (energy_max - energy_min) / float(np.float32(2) - np.float32(0.3))
+    b = (energy_max + energy_min) / 2
+    return a, b
+
+
+def _fc(a, dtype):
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Recursion:
+    """Drop-in counterpart of ``type(recursion)`` (recursion.f90:41-116)."""
+
+    def __init__(self, hamiltonian, lattice, control, energy=None, device=0, rank=0, nprocs=1):
+        self.hamiltonian, self.lattice, self.control, self.en = hamiltonian, lattice, control, energy or Energy()
+        self.rank, self.nprocs = rank, nprocs
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        rc = self._L.rsrec_create(C.byref(self._h), device)
+        if rc != 0:
+            raise _lib.RsrecError(rc, "rsrec_create failed (no usable gfx950 device? there is no CPU fallback)")
+        self.restore_to_default()
+        self.update_lattice()
+        self.update_hamiltonian()
+
+    # -- lifetime --------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.rsrec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            buf = C.create_string_buffer(512)
+            self._L.rsrec_last_error(self._h, buf, 512)
+            # the reference calls g_logger%fatal here (recursion.f90:1942, :2595)
+            raise _lib.RsrecError(rc, buf.value.decode(errors="replace"))
+
+    def set_option(self, key, value):
+        self._check(self._L.rsrec_set_option(self._h, key.encode(), int(value)))
+
+    def timing(self):
+        out = (C.c_double * 7)()
+        self._L.rsrec_get_timing(self._h, out, 7)
+        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms")
+        return dict(zip(keys, list(out)))
+
+    # -- state (restore_to_default, recursion.f90:3713-3825) --------------------------------------------
+    def restore_to_default(self):
+        lat, ctl = self.lattice, self.control
+        llmax = max(ctl.llsp, ctl.lld)
+        nrec = lat.nrec
+        njij = 0 if lat.ijpair is None else len(lat.ijpair)
+        nsites = nrec if njij == 0 else 4 * njij
+        self.a = np.zeros((llmax, 18, nrec, 3), np.float64, order="F")
+        self.b2 = np.zeros((llmax, 18, nrec, 3), np.float64, order="F")
+        self.a_b = np.zeros((18, 18, ctl.lld, nsites), np.complex128, order="F")
+        self.b2_b = np.zeros((18, 18, ctl.lld, nsites), np.complex128, order="F")
+        self.mu_n = np.zeros((18, 18, 2 * ctl.lld + 2, nsites), np.complex128, order="F")
+        self.mu_ng = np.zeros_like(self.mu_n)
+
+    def update_lattice(self):
+        lat = self.lattice
+        self._nn = _fc(lat.nn, np.int32)
+        self._iz = _fc(lat.iz, np.int32)
+        self._check(self._L.rsrec_set_lattice(self._h, lat.kk, self._nn.shape[1], _ptr(self._nn), _ptr(self._iz), int(lat.nmax), int(lat.ntype)))
+
+    def update_hamiltonian(self):
+        """Must be called whenever the caller rebuilt the blocks (self.f90:777-797 does before every recur*)."""
+        ham = self.hamiltonian
+        keep = {}
+        for k in ("ee", "lsham", "eeo", "enim", "hall", "hallo"):
+            v = getattr(ham, k)
+            keep[k] = None if v is None else _fc(v, np.complex128)
+        self._ham_keep = keep
+        self._check(self._L.rsrec_set_hamiltonian(self._h, keep["ee"].shape[2], int(bool(ham.hoh)), int(self.control.nsp),
+                                                  _ptr(keep["ee"]), _ptr(keep["lsham"]), _ptr(keep["eeo"]), _ptr(keep["enim"]),
+                                                  _ptr(keep["hall"]), _ptr(keep["hallo"])))
+
+    def _my_sites(self):
+        start, end = site_partition(self.rank, self.nprocs, self.lattice.nrec)   # recursion.f90:1816
+        return start, end, np.ascontiguousarray(self.lattice.irec[start - 1:end], dtype=np.int32)
+
+    # -- drivers ---------------------------------------------------------------------------------------
+    def recur_b(self):
+        """Block Lanczos for the sites this rank owns (recursion.f90:1807-1866)."""
+        lld = self.control.lld
+        start, end, seeds = self._my_sites()
+        n = len(seeds)
+        a_b = np.zeros((18, 18, lld, n), np.complex128, order="F")
+        b2_b = np.zeros_like(a_b)
+        self._check(self._L.rsrec_block_lanczos(self._h, n, _ptr(seeds), lld, _ptr(a_b), _ptr(b2_b)))
+        self.a_b[:, :, :, :n] = a_b                                   # index i - start_atom + 1 (:1847-1848)
+        self.b2_b[:, :, :, :n] = b2_b
+        d = np.arange(18)
+        self.a[:lld, :, :n, 0] = a_b[d, d].real.transpose(1, 0, 2)    # :1850-1851
+        self.b2[:lld, :, :n, 0] = b2_b[d, d].real.transpose(1, 0, 2)
+
+    def recur_b_ij(self):
+        """Four chains per atom pair, seeds (psi_i +- psi_j)/sqrt2 and (psi_i +- i psi_j)/sqrt2 (recursion.f90:1655-1800)."""
+        lld = self.control.lld
+        pairs = np.asarray(self.lattice.ijpair, dtype=np.int32)
+        njij = len(pairs)
+        start, end = site_partition(self.rank, self.nprocs, njij)
+        s2 = 1.0 / np.sqrt(2.0)          # one_over_sqrt_two (math.f90)
+        slots, seeds, coefs = [], [], []
+        for ij_loc, (i, j) in enumerate(pairs[start - 1:end]):
+            for reci in range(4):
+                if i == j:
+                    if reci > 0:
+                        continue                                      # :1705-1706 `cycle`: slots 2..4 stay zero
+                    seeds.append((i, i)); coefs.append((1.0, 0.0))    # :1702-1704
+                else:
+                    seeds.append((i, j)); coefs.append((s2, (s2, -s2, 1j * s2, -1j * s2)[reci]))   # :1679-1700
+                slots.append(ij_loc * 4 + reci)                       # ij_loc*4 - 4 + reci (:1721)
+        nch = len(seeds)
+        sa = np.ascontiguousarray(seeds, dtype=np.int32)
+        sc = np.ascontiguousarray(coefs, dtype=np.complex128)
+        a_b = np.zeros((18, 18, lld, nch), np.complex128, order="F")
+        b2_b = np.zeros_like(a_b)
+        self._check(self._L.rsrec_block_lanczos_seeded(self._h, nch, 2, _ptr(sa), _ptr(sc), lld, _ptr(a_b), _ptr(b2_b)))
+        self.a_b[:, :, :, slots] = a_b
+        self.b2_b[:, :, :, slots] = b2_b
+
+    def zsqr(self):
+        """b2_b <- sqrt(b2_b) in place (recursion.f90:1980-2023)."""
+        self._check(self._L.rsrec_zsqr(self._h, self.b2_b.shape[2] * self.b2_b.shape[3], _ptr(self.b2_b)))
+
+    def chebyshev_recur(self):
+        """Chebyshev moments for the sites this rank owns (recursion.f90:3057-3130)."""
+        lld = self.control.lld
+        a, b = chebyshev_scaling(self.en.energy_min, self.en.energy_max)
+        start, end, seeds = self._my_sites()
+        n = len(seeds)
+        mu = np.zeros((18, 18, 2 * lld + 2, n), np.complex128, order="F")
+        self._check(self._L.rsrec_chebyshev(self._h, n, _ptr(seeds), lld, a, b, _ptr(mu)))
+        self.mu_n[:, :, :, :n] = mu
+
+    def recur(self):
+        """Scalar Haydock recursion, 18 orbital chains per site (recursion.f90:3485-3532)."""
+        lld = self.control.lld
+        llmax = self.a.shape[0]
+        start, end, seeds = self._my_sites()
+        n = len(seeds)
+        a = np.zeros((llmax, 18, n), np.float64, order="F")
+        b2 = np.zeros_like(a)
+        self._check(self._L.rsrec_scalar_lanczos(self._h, n, _ptr(seeds), lld, llmax, _ptr(a), _ptr(b2)))
+        self.a[:, :, :n, 0] = a
+        self.b2[:, :, :n, 0] = b2

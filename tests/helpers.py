@@ -1,0 +1,56 @@
+"""Shared test helpers: build recursion problems from the committed golden fixtures."""
+import os
+
+import numpy as np
+
+from rslmtoasa_amd.lattice import bcc_supercell, spread_sites
+from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCALARS = ("kk", "nmax", "ntype", "nrec", "lld", "nsp", "hoh", "kind", "nslots", "emin", "emax", "acheb", "bcheb")
+
+BLOCK_CASES = ["bccFe_nsp2_block", "bccFe_nsp2_block_hoh", "bccFe_nsp4_block", "B2FeCo_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
+CHEB_CASES = ["bccFe_nsp2_cheb", "bccFe_nsp2_cheb_hoh", "fccCu001_cheb"]
+SCALAR_CASES = ["bccFe_nsp1_lanczos"]
+SUPERCELL_CASES = ["sc_4x4x8_block", "sc_4x4x8_block_hoh", "sc_4x4x8_cheb", "sc_22_block"]
+
+# Parity bar of BASELINE.json: 1e-10 relative on recursion coefficients / moments.
+RTOL = 1e-10
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}
+    for k in SCALARS + ("dims",):
+        if k in d and d[k].ndim == 0:
+            d[k] = d[k].item()
+    return d
+
+
+def rel_err(x, ref):
+    return float(np.abs(np.asarray(x) - np.asarray(ref)).max() / np.abs(ref).max())
+
+
+def problem_dict(g):
+    """oracle-style problem dict from a golden fixture."""
+    p = {k: g[k] for k in ("nn", "iz", "ee", "lsham", "eeo", "enim", "hall", "hallo") if k in g}
+    p.update(nmax=int(g.get("nmax", 0)), hoh=int(g.get("hoh", 0)), nsp=int(g.get("nsp", 2)))
+    return p
+
+
+def objects_from(p, irec, lld, nsp=2, emin=-1.0, emax=1.0, llsp=0):
+    ham = Hamiltonian(ee=p["ee"], lsham=p["lsham"], eeo=p.get("eeo"), enim=p.get("enim"), hall=p.get("hall"), hallo=p.get("hallo"),
+                      hoh=bool(p.get("hoh", 0)))
+    lat = Lattice(nn=p["nn"], iz=p["iz"], irec=np.asarray(irec, dtype=np.int32), nmax=int(p.get("nmax", 0)), ntype=p["ee"].shape[3])
+    return ham, lat, Control(lld=lld, llsp=llsp, nsp=nsp), Energy(emin, emax)
+
+
+def supercell_problem(dims, hoh=False):
+    """Synthetic periodic bcc Fe supercell with the stencil dumped from the reference's bccFe case."""
+    st = load_golden("bccFe_nsp2_block_hoh" if hoh else "bccFe_nsp2_block")
+    vec = load_golden("bccFe_nsp2_block")["slot_vec"]
+    nn = bcc_supercell(dims, vec)
+    p = dict(nn=nn, iz=np.ones(nn.shape[0], np.int32), ee=st["ee"], lsham=st["lsham"], hoh=int(hoh), nsp=2, nmax=0)
+    if hoh:
+        p.update(eeo=st["eeo"], enim=st["enim"])
+    return p
