@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the recursion hot path (BASELINE.json).
+
+Workload (configs[1] of BASELINE.json): bcc Fe periodic supercell 22^3 = 10 648 atoms, spin-polarised 18x18
+complex blocks (physical Fe stencil dumped from the reference's tests/scf/cases/bulk/bccFe), block-Lanczos
+recursion with LL = 50.  One "step" = one full `recur_b` pass (recursion.f90:1807) over a batch of S = 64
+recursion sites per GPU: 49 recursion levels of H|psi>, A_n, B_n^2, 18x18 eigen-solve and vector update for
+every site.  Lattice tables and Hamiltonian blocks are resident in HBM before the timed region; the timed
+region contains everything `recur_b` does per call (region search, kernels, coefficients back to the host)
+and, for N > 1, the one packed RCCL all-reduce that gathers the per-site diagonal coefficients exactly like
+the reference's MPI_ALLREDUCE-as-allgather (bands.f90:271-274).
+
+Sites are independent: with N GPUs every rank owns S sites (weak scaling), no collective inside the loop.
+
+usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from rslmtoasa_amd.lattice import bcc_supercell, spread_sites  # noqa: E402
+from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); rate measured here: profiles/ubench_f64_r01.txt
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
+BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
+
+
+def load_stencil():
+    with np.load(os.path.join(ROOT, "tests", "golden", "bccFe_nsp2_block.npz"), allow_pickle=False) as z:
+        return z["ee"], z["lsham"], z["slot_vec"]
+
+
+def cpu_baseline(nn, ee, lsham, lld, threads):
+    """CPU leg on the host cores of this node, bounded sample = ONE site of the same workload (same lattice, LL).
+
+    Preferred: the compiled reference itself (oracle/_ref/ref_kernel.x, built in the build container from the
+    reference sources; it is the reference's own recur_b/crecal_b/hop_b with MKL + OpenMP).  Fallback: the C
+    restatement in oracle/ ("port")."""
+    flop = None
+    from rslmtoasa_amd.lattice import active_region_sizes
+    sizes = [1] + active_region_sizes(nn, 1, lld - 1)
+    # exact algorithmic work of one chain (matches SURVEY.md 8d: 384.7 GFLOP for this config)
+    nb = int(nn[0, 0])
+    mults = sum(nb * s for s in sizes[:-1])
+    atom_steps = sum(sizes[1:])
+    flop = FLOP_PER_BLOCK_MULT * (mults + 5 * atom_steps)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_kernel.x")
+    if os.path.exists(exe):
+        try:
+            sys.path.insert(0, ROOT)
+            from oracle import fixture_io as fio
+            scratch = tempfile.mkdtemp(prefix="rsrec_cpu_")
+            kk = nn.shape[0]
+            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=np.array([1], np.int32), lld=lld, nsp=2, hoh=0, kind=0, ee=ee, lsham=lsham)
+            fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G")
+            r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=scratch, env=env, capture_output=True, text=True, timeout=600)
+            t = None
+            for line in r.stdout.splitlines():
+                if "recursion wall time" in line:
+                    t = float(line.split()[-2])
+            if r.returncode == 0 and t:
+                return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "kind": "reference", "seconds": t,
+                        "sample": "1 site of the same 10648-atom cell, LL=%d (%.1f GFLOP), compiled reference recur_b via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (lld, flop * 1e-9)}
+        except Exception as e:  # noqa
+            print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
+    from oracle import oracle
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    o = oracle.Oracle(dict(nn=nn, iz=np.ones(nn.shape[0], np.int32), ee=ee, lsham=lsham, hoh=0, nsp=2))
+    t0 = time.time()
+    o.block_lanczos(np.array([1], np.int32), lld)
+    t = time.time() - t0
+    return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "kind": "port", "seconds": t,
+            "sample": "1 site of the same 10648-atom cell, LL=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (lld, flop * 1e-9)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sites", type=int, default=64, help="recursion sites per GPU per step")
+    ap.add_argument("--cells", type=int, default=22, help="n for the n^3 periodic bcc supercell")
+    ap.add_argument("--lld", type=int, default=50)
+    ap.add_argument("--kernels", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+
+    ee, lsham, slot_vec = load_stencil()
+    n = args.cells
+    nn = bcc_supercell((n, n, n), slot_vec)
+    kk = nn.shape[0]
+    nsites_total = args.sites * world
+    irec = spread_sites(kk, nsites_total)
+    lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1)
+    ham = Hamiltonian(ee=ee, lsham=lsham, hoh=False)
+    ctl = Control(lld=args.lld, nsp=2, recur="block")
+    rec = Recursion(ham, lat, ctl, Energy(), device=local_rank, rank=rank, nprocs=world)   # uploads tables: resident before timing
+    if args.kernels:
+        rec.set_option("kernels", args.kernels)
+    if args.batch:
+        rec.set_option("batch", args.batch)
+
+    gather = None
+    if world > 1:
+        gather = torch.zeros((2, args.lld, 18, nsites_total), dtype=torch.float64, device="cuda")
+
+    def step():
+        rec.recur_b()
+        if world > 1:
+            # the path's one exchange: zero-padded all-reduce == all-gather of per-site results (bands.f90:271-274)
+            start, end = rec._my_sites()[:2]
+            nloc = end - start + 1
+            gather.zero_()
+            gather[0, :, :, start - 1:end] = torch.from_numpy(np.ascontiguousarray(rec.a[:args.lld, :, :nloc, 0])).cuda()
+            gather[1, :, :, start - 1:end] = torch.from_numpy(np.ascontiguousarray(rec.b2[:args.lld, :, :nloc, 0])).cuda()
+            dist.all_reduce(gather, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    tm_acc = {"hop_ms": 0.0, "hop_launches": 0.0, "atom_steps": 0.0, "block_multiplies": 0.0, "total_ms": 0.0, "host_ms": 0.0}
+    for _ in range(args.steps):
+        step()
+        tm = rec.timing()
+        for k in tm_acc:
+            tm_acc[k] += tm[k]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
+        flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + 5.0 * tm_acc["atom_steps"])
+        flop_total = flop_rank * world
+        bytes_total = BYTES_PER_ATOM_STEP * tm_acc["atom_steps"] * world
+        # dominant kernel = H|psi> (SpMM + fused pmn update + A_n partial): 46656*(block multiplies + 1 per atom-step for A_n)
+        hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + tm_acc["atom_steps"])
+        hop_s = tm_acc["hop_ms"] * 1e-3
+        achieved = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
+        out = {
+            "metric": "block-recursion throughput (H|psi> + A_n + B_n recursion levels, recursion.f90 recur_b)",
+            "value": flop_total / elapsed * 1e-9,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic periodic bcc lattice; physical Fe spd stencil (18x18 complex blocks) dumped from the reference's bulk/bccFe case",
+            "config": {"workload": "bcc Fe %d^3 = %d atoms, nsp=2 18x18 blocks, block Lanczos LL=%d, %d sites per GPU per step" % (n, kk, args.lld, args.sites),
+                       "sites_per_gpu": args.sites, "atoms": kk, "lld": args.lld, "parallelism": "site-partition x%d (get_mpi_variables rule), no collective in the loop" % world},
+            "sites_per_s": nsites_total * args.steps / elapsed,
+            "atom_steps_per_s": tm_acc["atom_steps"] * world / elapsed,
+            "gbytes_per_s": bytes_total / elapsed * 1e-9,
+            "device_ms_per_step": tm_acc["total_ms"] / args.steps,
+            "host_ms_per_step": tm_acc["host_ms"] / args.steps,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": None, "kernel": "H|psi> (hop)", "launches": tm_acc["hop_launches"],
+                         "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
+                         "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
+                                      "note": "whole recursion level, algorithmic 51840 B per atom-step"}},
+        }
+        if world == 1 and not args.no_cpu:
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(nn, ee, lsham, args.lld, threads)
+        print(json.dumps(out))
+    rec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

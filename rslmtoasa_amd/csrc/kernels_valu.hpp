@@ -13,6 +13,20 @@ namespace rsrec {
 
 constexpr int NB = 18;
 constexpr int BLK = 324;            // complex elements per block
+constexpr int BLD = 648;            // doubles per block (both layouts)
+
+// Work-vector layouts.  A block is 648 doubles either way.
+//  LayoutCM: the reference's own storage, complex(8) column-major interleaved: (r,c) -> re at 2*(r+18c), im next to it.
+//  LayoutRM: "row-major planar", the MFMA kernels' layout: (r,c) -> re at 36r+c, im at 36r+18+c.  Rows of 36 doubles
+//            [re(0..17) | im(0..17)] are what v_mfma_f64_16x16x4 wants as B operand (k = row, n = column on the lanes).
+struct LayoutCM {
+    static __device__ __forceinline__ double2 ld(const double* b, int r, int c) { return reinterpret_cast<const double2*>(b)[r + NB * c]; }
+    static __device__ __forceinline__ void st(double* b, int r, int c, double2 v) { reinterpret_cast<double2*>(b)[r + NB * c] = v; }
+};
+struct LayoutRM {
+    static __device__ __forceinline__ double2 ld(const double* b, int r, int c) { return make_double2(b[36 * r + c], b[36 * r + 18 + c]); }
+    static __device__ __forceinline__ void st(double* b, int r, int c, double2 v) { b[36 * r + c] = v.x; b[36 * r + 18 + c] = v.y; }
+};
 constexpr int TILE_ATOMS = 14;      // 14 atoms x 18 = 252 of 256 threads
 constexpr int NTHREADS = 256;
 
@@ -32,7 +46,7 @@ struct ChainView {           // per launch: a batch of chains with identical str
     const int* order;        // [nchain][kk]
     const int* cum;          // [nchain][nlev]
     int nlev;
-    size_t vstride;          // elements (double2) between chains in a work vector = kk*324
+    size_t vstride;          // doubles between chains in a work vector = (kk+1)*648 (last block is an all-zero block)
     int cpo;                 // chains sharing one order/cum row (1; 18 for the scalar recursion's orbital chains)
     int kk;
     __device__ __forceinline__ const int* order_of(int chain) const { return order + (size_t)(chain / cpo) * kk; }
@@ -54,25 +68,27 @@ __device__ __forceinline__ const double2* op_block(const DevProblem& P, bool o, 
 }
 
 // acc[r] += sum_slots H(slot)[r,:] * in_{nbr(i,slot)}[:,c]
-__device__ __forceinline__ void apply_column(const DevProblem& P, bool o, int i, const double2* __restrict__ in, int c, double2 acc[NB]) {
+template <class L>
+__device__ __forceinline__ void apply_column(const DevProblem& P, bool o, int i, const double* __restrict__ in, int c, double2 acc[NB]) {
     const int* nb = P.nbr + (size_t)P.nslots * i;
     for (int slot = 0; slot < P.nslots; ++slot) {
         const int n = nb[slot];
         if (n < 0) continue;
-        const double2* x = in + (size_t)BLK * n + NB * c;
+        const double* x = in + (size_t)BLD * n;
         const double2* H = op_block(P, o, i, slot);
 #pragma unroll 2
         for (int k = 0; k < NB; ++k) {
-            const double2 xk = x[k];
+            const double2 xk = L::ld(x, k, c);
 #pragma unroll
             for (int r = 0; r < NB; ++r) cfma(acc[r], H[r + NB * k], xk);
         }
     }
 }
 // acc[r] += M[r,:] * x[:,c] for a single per-type block
-__device__ __forceinline__ void apply_block_col(const double2* __restrict__ M, const double2* __restrict__ xblk, int c, double2 acc[NB]) {
+template <class L>
+__device__ __forceinline__ void apply_block_col(const double2* __restrict__ M, const double* __restrict__ xblk, int c, double2 acc[NB]) {
     for (int k = 0; k < NB; ++k) {
-        const double2 xk = xblk[k + NB * c];
+        const double2 xk = L::ld(xblk, k, c);
 #pragma unroll
         for (int r = 0; r < NB; ++r) cfma(acc[r], M[r + NB * k], xk);
     }
@@ -102,17 +118,17 @@ enum ApplyMode {
 };
 
 struct ApplyArgs {
-    const double2* in;     // vector the neighbour sum runs over (psi | hpsi | psi1)
-    const double2* v0;     // psi (Lanczos) | psi0 (Chebyshev)
-    const double2* v1;     // hoh second pass: hpsi (first-pass result) ; Chebyshev hoh: same
-    double2* out;          // pmn | hpsi | psi1 | psi2
-    const double2* cur;    // Chebyshev: psi1 (the vector H was applied to in pass 1); Lanczos hoh: psi
+    const double* in;      // vector the neighbour sum runs over (psi | hpsi | psi1)
+    const double* v0;      // psi (Lanczos) | psi0 (Chebyshev)
+    const double* v1;      // hoh second pass: hpsi (first-pass result) ; Chebyshev hoh: same
+    double* out;           // pmn | hpsi | psi1 | psi2
+    const double* cur;     // Chebyshev: psi1 (the vector H was applied to in pass 1); Lanczos hoh: psi
     double2* partial;      // [nchain][nblk][nk][324]
     int level;             // region = order[0 .. cum[level])
     double a, b;
 };
 
-template <int MODE>
+template <int MODE, class L>
 __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, ApplyArgs G) {
     __shared__ double2 red[BLK];
     const int chain = blockIdx.y;
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
     const int count = CV.count_of(chain, G.level);
     const int* order = CV.order_of(chain);
     const size_t vo = (size_t)chain * CV.vstride;
-    const double2* in = G.in + vo;
+    const double* in = G.in + vo;
     constexpr bool second_pass = (MODE == AM_HOH_LANCZOS || MODE == AM_HOH_CHEB1 || MODE == AM_HOH_CHEBN);
     constexpr int nk = (MODE == AM_CHEBN || MODE == AM_HOH_CHEBN) ? 2 : 1;
     double2 part0[NB], part1[NB];
@@ -131,65 +147,66 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
         const int t = tile * TILE_ATOMS + a;
         if (a >= TILE_ATOMS || t >= count) continue;
         const int i = order[t];
-        const size_t bo = (size_t)BLK * i;
+        if (i < 0) continue;                       // padding entry of a type-homogeneous group list
+        const size_t bo = vo + (size_t)BLD * i;
         double2 acc[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) acc[r] = make_double2(0, 0);
-        apply_column(P, second_pass, i, in, c, acc);
+        apply_column<L>(P, second_pass, i, in, c, acc);
         if (MODE == AM_STORE) {
 #pragma unroll
-            for (int r = 0; r < NB; ++r) G.out[vo + bo + r + NB * c] = acc[r];
+            for (int r = 0; r < NB; ++r) L::st(G.out + bo, r, c, acc[r]);
             continue;
         }
         if (second_pass) {
             // acc = (h*o) applied to hpsi ; total = hpsi_i - acc + enim*x_i + lsham*x_i   (x = psi | psi0 | psi1)
-            const double2* x = G.cur + vo + bo;
+            const double* x = G.cur + bo;
             double2 t2[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) { const double2 h = G.v1[vo + bo + r + NB * c]; t2[r] = make_double2(h.x - acc[r].x, h.y - acc[r].y); acc[r] = make_double2(0, 0); }
-            apply_block_col(P.enim + (size_t)BLK * P.iz[i], x, c, acc);
+            for (int r = 0; r < NB; ++r) { const double2 h = L::ld(G.v1 + bo, r, c); t2[r] = make_double2(h.x - acc[r].x, h.y - acc[r].y); acc[r] = make_double2(0, 0); }
+            apply_block_col<L>(P.enim + (size_t)BLK * P.iz[i], x, c, acc);
 #pragma unroll
             for (int r = 0; r < NB; ++r) { t2[r].x += acc[r].x; t2[r].y += acc[r].y; acc[r] = make_double2(0, 0); }
-            apply_block_col(P.lsham + (size_t)BLK * P.iz[i], x, c, acc);
+            apply_block_col<L>(P.lsham + (size_t)BLK * P.iz[i], x, c, acc);
 #pragma unroll
             for (int r = 0; r < NB; ++r) { acc[r].x += t2[r].x; acc[r].y += t2[r].y; }
         }
         if (MODE == AM_LANCZOS || MODE == AM_HOH_LANCZOS) {
-            const double2* psi = G.v0 + vo + bo;
+            const double* psi = G.v0 + bo;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const double2 p = G.out[vo + bo + r + NB * c];
-                G.out[vo + bo + r + NB * c] = make_double2(acc[r].x - p.x, acc[r].y - p.y);
+                const double2 p = L::ld(G.out + bo, r, c);
+                L::st(G.out + bo, r, c, make_double2(acc[r].x - p.x, acc[r].y - p.y));
             }
 #pragma unroll
             for (int cp = 0; cp < NB; ++cp) {
 #pragma unroll
-                for (int r = 0; r < NB; ++r) cfma_conj(part0[cp], psi[r + NB * cp], acc[r]);
+                for (int r = 0; r < NB; ++r) cfma_conj(part0[cp], L::ld(psi, r, cp), acc[r]);
             }
         } else {
             // Chebyshev: x = vector H was applied to (psi0 for the first moment, psi1 afterwards)
-            const double2* x = G.cur + vo + bo;
+            const double* x = G.cur + bo;
             const bool first = (MODE == AM_CHEB1 || MODE == AM_HOH_CHEB1);
             double2 nv[NB];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const double2 xr = x[r + NB * c];
+                const double2 xr = L::ld(x, r, c);
                 double vx = acc[r].x - G.b * xr.x, vy = acc[r].y - G.b * xr.y;
                 vx = vx / G.a; vy = vy / G.a;
                 if (!first) {
                     vx = 2.0 * vx; vy = 2.0 * vy;
-                    const double2 p0 = G.v0[vo + bo + r + NB * c];
+                    const double2 p0 = L::ld(G.v0 + bo, r, c);
                     vx -= p0.x; vy -= p0.y;
                 }
                 nv[r] = make_double2(vx, vy);
-                G.out[vo + bo + r + NB * c] = nv[r];
+                L::st(G.out + bo, r, c, nv[r]);
             }
             if (first) {
-                const double2* p0 = G.v0 + vo + bo;   // psi0^H psi1
+                const double* p0 = G.v0 + bo;   // psi0^H psi1
 #pragma unroll
                 for (int cp = 0; cp < NB; ++cp) {
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) cfma_conj(part0[cp], p0[r + NB * cp], nv[r]);
+                    for (int r = 0; r < NB; ++r) cfma_conj(part0[cp], L::ld(p0, r, cp), nv[r]);
                 }
             } else {
                 // d1[cp][c] += psi1[:,cp]^H psi1[:,c] ; d2[cp][c] += psi2[:,cp]^H psi1[:,c]: this thread owns column c of
@@ -197,12 +214,12 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
                 // d2[c][cp] = conj( psi1[:,cp]^H psi2[:,c] ), fixed up in the reduction kernel.
                 double2 x1c[NB];
 #pragma unroll
-                for (int r = 0; r < NB; ++r) x1c[r] = x[r + NB * c];
+                for (int r = 0; r < NB; ++r) x1c[r] = L::ld(x, r, c);
 #pragma unroll
                 for (int cp = 0; cp < NB; ++cp) {
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
-                        const double2 x1 = x[r + NB * cp];
+                        const double2 x1 = L::ld(x, r, cp);
                         cfma_conj(part0[cp], x1, x1c[r]);
                         cfma_conj(part1[cp], x1, nv[r]);
                     }
@@ -222,8 +239,41 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
     }
 }
 
-// K2: pmn_i <- pmn_i - psi_i * A ; B2 += pmn_i^H pmn_i      crecal_b :1922-1934
-__global__ __launch_bounds__(NTHREADS) void k_orth(int kk, ChainView CV, int level, const double2* __restrict__ psi, double2* pmn,
+// A partial only: A += psi_i^H t_i  (t = H psi already stored by an SpMM kernel)            hop_b :1642
+template <class L>
+__global__ __launch_bounds__(NTHREADS) void k_adot(ChainView CV, int level, const double* __restrict__ psi, const double* __restrict__ tvec, double2* partial) {
+    __shared__ double2 red[BLK];
+    const int chain = blockIdx.y;
+    const int a = threadIdx.x / NB, c = threadIdx.x % NB;
+    const int count = CV.count_of(chain, level);
+    const int* order = CV.order_of(chain);
+    const size_t vo = (size_t)chain * CV.vstride;
+    double2 part[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) part[r] = make_double2(0, 0);
+    for (int tile = blockIdx.x; tile * TILE_ATOMS < count; tile += gridDim.x) {
+        const int t = tile * TILE_ATOMS + a;
+        if (a >= TILE_ATOMS || t >= count) continue;
+        const int i = order[t];
+        if (i < 0) continue;
+        const size_t bo = vo + (size_t)BLD * i;
+        double2 tc[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) tc[r] = L::ld(tvec + bo, r, c);
+#pragma unroll
+        for (int cp = 0; cp < NB; ++cp) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) cfma_conj(part[cp], L::ld(psi + bo, r, cp), tc[r]);
+        }
+    }
+    block_reduce_cols(red, part, a, c, a < TILE_ATOMS);
+    double2* pout = partial + ((size_t)chain * gridDim.x + blockIdx.x) * BLK;
+    for (int e = threadIdx.x; e < BLK; e += blockDim.x) pout[e] = red[e];
+}
+
+// K2: pmn_i <- [t_i -] pmn_i - psi_i * A ; B2 += pmn_i^H pmn_i      crecal_b :1922-1934 (+ hop_b :1641 when tvec != null)
+template <class L>
+__global__ __launch_bounds__(NTHREADS) void k_orth(ChainView CV, int level, const double* __restrict__ psi, double* pmn, const double* __restrict__ tvec,
                                                    const double2* __restrict__ Amat /*[nchain] stride astride*/, size_t astride, double2* partial) {
     __shared__ double2 As[BLK];
     __shared__ double2 red[BLK];
@@ -241,12 +291,17 @@ __global__ __launch_bounds__(NTHREADS) void k_orth(int kk, ChainView CV, int lev
     __syncthreads();
     for (int tile = blockIdx.x; tile * TILE_ATOMS < count; tile += gridDim.x) {
         const int t = tile * TILE_ATOMS + a;
-        const bool valid = a < TILE_ATOMS && t < count;
+        const int i = (a < TILE_ATOMS && t < count) ? order[t] : -1;
+        const bool valid = i >= 0;
         if (valid) {
-            const size_t bo = vo + (size_t)BLK * order[t];
+            const size_t bo = vo + (size_t)BLD * i;
             double2 prow[NB], srow[NB];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) { srow[k] = psi[bo + r + NB * k]; prow[k] = pmn[bo + r + NB * k]; }
+            for (int k = 0; k < NB; ++k) { srow[k] = L::ld(psi + bo, r, k); prow[k] = L::ld(pmn + bo, r, k); }
+            if (tvec) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { const double2 h = L::ld(tvec + bo, r, k); prow[k] = make_double2(h.x - prow[k].x, h.y - prow[k].y); }
+            }
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 double2 acc = make_double2(0, 0);
@@ -255,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS) void k_orth(int kk, ChainView CV, int lev
                 prow[c].x -= acc.x; prow[c].y -= acc.y;
             }
 #pragma unroll
-            for (int c = 0; c < NB; ++c) { pmn[bo + r + NB * c] = prow[c]; tilebuf[a * BLK + r + NB * c] = prow[c]; }
+            for (int c = 0; c < NB; ++c) { L::st(pmn + bo, r, c, prow[c]); tilebuf[a * BLK + r + NB * c] = prow[c]; }
         }
         __syncthreads();
         if (valid) {
@@ -275,7 +330,8 @@ __global__ __launch_bounds__(NTHREADS) void k_orth(int kk, ChainView CV, int lev
 }
 
 // K3: psi_i <- pmn_i * Binv ; pmn_i <- psi_old_i * B       crecal_b :1963-1969
-__global__ __launch_bounds__(NTHREADS) void k_update(int kk, ChainView CV, int level, double2* psi, double2* pmn, const double2* __restrict__ Bmats /*[nchain][2][324]: B, Binv*/) {
+template <class L>
+__global__ __launch_bounds__(NTHREADS) void k_update(ChainView CV, int level, double* psi, double* pmn, const double2* __restrict__ Bmats /*[nchain][2][324]: B, Binv*/) {
     __shared__ double2 Bs[BLK], Bis[BLK];
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, r = threadIdx.x % NB;
@@ -287,16 +343,18 @@ __global__ __launch_bounds__(NTHREADS) void k_update(int kk, ChainView CV, int l
     for (int tile = blockIdx.x; tile * TILE_ATOMS < count; tile += gridDim.x) {
         const int t = tile * TILE_ATOMS + a;
         if (a >= TILE_ATOMS || t >= count) continue;
-        const size_t bo = vo + (size_t)BLK * order[t];
+        const int i = order[t];
+        if (i < 0) continue;
+        const size_t bo = vo + (size_t)BLD * i;
         double2 prow[NB], srow[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { srow[k] = psi[bo + r + NB * k]; prow[k] = pmn[bo + r + NB * k]; }
+        for (int k = 0; k < NB; ++k) { srow[k] = L::ld(psi + bo, r, k); prow[k] = L::ld(pmn + bo, r, k); }
         for (int c = 0; c < NB; ++c) {
             double2 x = make_double2(0, 0), y = make_double2(0, 0);
 #pragma unroll
             for (int k = 0; k < NB; ++k) { cfma(x, prow[k], Bis[k + NB * c]); cfma(y, srow[k], Bs[k + NB * c]); }
-            psi[bo + r + NB * c] = x;
-            pmn[bo + r + NB * c] = y;
+            L::st(psi + bo, r, c, x);
+            L::st(pmn + bo, r, c, y);
         }
     }
 }
@@ -390,14 +448,16 @@ __global__ __launch_bounds__(1024) void k_reduce_cheb(const double2* __restrict_
 }
 
 // psi(:,:,seed) = coef * I18 for every seed of every chain
-__global__ void k_seed(double2* psi, size_t vstride, const int* seed_atoms, const double2* seed_coef, int nseed) {
+template <class L>
+__global__ void k_seed(double* psi, size_t vstride, const int* seed_atoms, const double2* seed_coef, int nseed) {
     const int chain = blockIdx.x;
     for (int s = 0; s < nseed; ++s) {
         const int atom = seed_atoms[chain * nseed + s];
         const double2 cf = seed_coef[chain * nseed + s];
         if (threadIdx.x < NB) {
-            double2* p = psi + chain * vstride + (size_t)BLK * atom + threadIdx.x * (NB + 1);
-            p->x += cf.x; p->y += cf.y;
+            double* b = psi + chain * vstride + (size_t)BLD * atom;
+            const double2 v = L::ld(b, threadIdx.x, threadIdx.x);
+            L::st(b, threadIdx.x, threadIdx.x, make_double2(v.x + cf.x, v.y + cf.y));
         }
     }
 }

@@ -491,10 +491,10 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
                 G.in = hpsi; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
                 k_apply<AM_HOH_LANCZOS><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             }
-            k_reduce_a<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dA + (size_t)ll * BLK, cstride);
-            hipEvent_t e1 = next_event(h);
+            hipEvent_t e1 = next_event(h);                     // [e0,e1] brackets exactly the H|psi> kernel(s) of this step
             hop_ev.emplace_back(e0, e1);
             h->n_hop_launch += hoh ? 2 : 1;
+            k_reduce_a<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dA + (size_t)ll * BLK, cstride);
             k_orth<<<grid, NTHREADS, TILE_ATOMS * BLK * sizeof(double2), h->stream>>>(kk, CV, lv_final, psi, pmn, dA + (size_t)ll * BLK, cstride, h->d_partial.as<double2>());
             k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
             k_update<<<grid, NTHREADS, 0, h->stream>>>(kk, CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
@@ -613,10 +613,10 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
                 if (first) k_apply<AM_HOH_CHEB1><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 else k_apply<AM_HOH_CHEBN><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             }
-            k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>());
             hipEvent_t e1 = next_event(h);
             hop_ev.emplace_back(e0, e1);
             h->n_hop_launch += hoh ? 2 : 1;
+            k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>());
             if (!first) { double2* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
         }
         HIPCK(h, hipGetLastError());

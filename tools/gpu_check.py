@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Diagnostic run on the GPU box: every golden case through the HIP path, errors and timings printed."""
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import *  # noqa
+from rslmtoasa_amd.recursion import Recursion
+from rslmtoasa_amd.lattice import spread_sites
+
+
+def run(label, fn):
+    t = time.time()
+    try:
+        msg = fn()
+    except Exception as e:  # noqa
+        msg = "EXC " + repr(e)[:300]
+        traceback.print_exc()
+    print("%-44s %s  [%.2fs]" % (label, msg, time.time() - t), flush=True)
+
+
+def block(name, kernels):
+    g = load_golden(name)
+    ham, lat, ctl, en = objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
+    rec = Recursion(ham, lat, ctl, en)
+    rec.set_option("kernels", kernels)
+    rec.recur_b()
+    n = g["nrec"]
+    tm = rec.timing()
+    msg = "a_b %.2e b2_b %.2e  dev %.2f ms hop %.2f ms" % (rel_err(rec.a_b[:, :, :, :n], g["a_b"]), rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]), tm["total_ms"], tm["hop_ms"])
+    rec.close()
+    return msg
+
+
+def cheb(name):
+    g = load_golden(name)
+    ham, lat, ctl, en = objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], emin=g["emin"], emax=g["emax"])
+    rec = Recursion(ham, lat, ctl, en)
+    rec.chebyshev_recur()
+    tm = rec.timing()
+    msg = "mu %.2e dev %.2f ms" % (rel_err(rec.mu_n[:, :, :, : g["nrec"]], g["mu_n"]), tm["total_ms"])
+    rec.close()
+    return msg
+
+
+def scalar(name):
+    g = load_golden(name)
+    ham, lat, ctl, en = objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], llsp=g["a"].shape[0])
+    rec = Recursion(ham, lat, ctl, en)
+    rec.recur()
+    msg = "a %.2e b2 %.2e" % (rel_err(rec.a[:, :, :, 0], g["a"]), rel_err(rec.b2[:, :, :, 0], g["b2"]))
+    rec.close()
+    return msg
+
+
+def supercell(name, kernels, nsites=1):
+    g = load_golden(name)
+    p = supercell_problem(g["dims"], hoh=bool(g["hoh"]))
+    kk = p["nn"].shape[0]
+    sites = g["irec"] if nsites <= len(g["irec"]) else spread_sites(kk, nsites)
+    ham, lat, ctl, en = objects_from(p, sites, int(g["lld"]), emin=float(g["emin"]), emax=float(g["emax"]))
+    rec = Recursion(ham, lat, ctl, en)
+    rec.set_option("kernels", kernels)
+    if int(g["kind"]) == 0:
+        rec.recur_b()
+        n = len(g["irec"])
+        err = [rel_err(rec.a_b[:, :, :l, :n], g["a_b"][:, :, :l]) for l in (10, 20, int(g["lld"]))]
+        tm = rec.timing()
+        fl = 46656.0 * (tm["block_multiplies"] + 5 * tm["atom_steps"])
+        msg = "a_b(10/20/all) %.1e %.1e %.1e  dev %.2f ms hop %.2f ms host %.1f ms  %.1f GFLOP -> %.2f TF/s" % (*err, tm["total_ms"], tm["hop_ms"], tm["host_ms"], fl * 1e-9, fl / tm["total_ms"] * 1e-9)
+    else:
+        rec.chebyshev_recur()
+        tm = rec.timing()
+        msg = "mu %.2e dev %.2f ms" % (rel_err(rec.mu_n[:, :, :, :1], g["mu_n"]), tm["total_ms"])
+    rec.close()
+    return msg
+
+
+if __name__ == "__main__":
+    ks = [int(x) for x in os.environ.get("RSREC_KERNELS", "1").split(",")]
+    for k in ks:
+        for name in BLOCK_CASES:
+            run("block %s k=%d" % (name, k), lambda: block(name, k))
+    for name in CHEB_CASES:
+        run("cheb %s" % name, lambda: cheb(name))
+    for name in SCALAR_CASES:
+        run("scalar %s" % name, lambda: scalar(name))
+    for k in ks:
+        for name in SUPERCELL_CASES:
+            run("supercell %s k=%d" % (name, k), lambda: supercell(name, k))
+        run("supercell sc_22_block k=%d x16 sites" % k, lambda: supercell("sc_22_block", k, 16))
