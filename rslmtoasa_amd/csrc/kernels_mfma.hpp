@@ -83,11 +83,33 @@ struct SpmmArgs {
     int level;
 };
 
+// XCD-aware work split: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, guide T1), and each
+// XCD has its own 4 MiB L2.  Every psi block is read by ~15 neighbouring atoms, so groups that are close in the region order
+// must run on the SAME XCD for those re-reads to hit L2: XCD x owns the contiguous chunk x of the group list and its resident
+// workgroups sweep that chunk as a sliding window.  Placement only affects speed, never results.
+struct GroupWalk {
+    int g, end, step;
+    __device__ __forceinline__ GroupWalk(int ngroups, int wave) {
+        const int nbx = gridDim.x, bx = blockIdx.x;
+        const int xcd = bx & 7, j = bx >> 3;
+        const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);       // workgroups that share this XCD label
+        const int chunk = (ngroups + 7) >> 3;
+        const int lo = xcd * chunk;
+        end = min(ngroups, lo + chunk);
+        g = lo + j * MF_WAVES + wave;
+        step = per_xcd * MF_WAVES;
+        if (nbx < 8) { g = bx * MF_WAVES + wave; end = ngroups; step = nbx * MF_WAVES; }
+    }
+};
+
 // out_i = sum_slots H_slot * in_{nbr(i,slot)} for every atom of the (padded, type-homogeneous) order prefix.
-// One wave = one group of 8 atoms.  Group entries < 0 are padding.
-__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_spmm(DevProblem P, ChainView CV, SpmmArgs G) {
+// One wave = one group of 8 atoms.  Group entries < 0 are padding.  Operand fragments are software-pipelined one k-step
+// ahead in registers (hipcc otherwise waits for every load right before its three MFMAs).
+template <int WPS>
+__global__ __launch_bounds__(MF_WAVES * 64, WPS) void k_mfma_spmm(DevProblem P, ChainView CV, SpmmArgs G) {
     const int chain = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: group bookkeeping lives in SGPRs
     const int count = CV.count_of(chain, G.level);          // multiple of GROUP
     const int ngroups = count / GROUP;
     const int* order = CV.order_of(chain);
@@ -96,9 +118,13 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_spmm(DevProblem P, Ch
     double* out = G.out + vo;
     const int zero_block = P.kk;                              // index of the all-zero block (absent neighbours, padding)
     const int l15 = lane & 15, l4 = lane >> 4;
+    // per-lane element offset of k-row (4q + l4) inside a block: kappa = 18*part + r -> 36 r + 18 part
+    int koff[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const int kap = 4 * q + l4; koff[q] = (kap < 18) ? 36 * kap : 36 * (kap - 18) + 18; }
 
-    for (int g = blockIdx.x * MF_WAVES + wave; g < ngroups; g += gridDim.x * MF_WAVES) {
-        const int* grp = order + (size_t)g * GROUP;
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
         int atom[GROUP];
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) atom[t] = grp[t];
@@ -107,39 +133,63 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_spmm(DevProblem P, Ch
         const int my_rem_atom = grp[l15 >> 1];                 // remainder tile: lane -> (atom (l15>>1), column 16 + (l15&1))
         const double* fr = G.frag + (size_t)tau * P.nslots * FRAG_PER_SLOT + lane;
 
+        auto load_src = [&](int s, unsigned (&src)[9]) {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                int n = atom[t] >= 0 ? P.nbr[(size_t)P.nslots * atom[t] + s] : -1;
+                if (n < 0) n = zero_block;
+                src[t] = (unsigned)BLD * n + l15;              // column l15 of the atom-aligned tile
+            }
+            int n = my_rem_atom >= 0 ? P.nbr[(size_t)P.nslots * my_rem_atom + s] : -1;
+            if (n < 0) n = zero_block;
+            src[8] = (unsigned)BLD * n + 16 + (l15 & 1);
+        };
+
         double4_t acc0[9], acc1[9];
         double acc2[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { acc0[t] = (double4_t){0, 0, 0, 0}; acc1[t] = (double4_t){0, 0, 0, 0}; acc2[t] = 0.0; }
 
-        for (int s = 0; s < P.nslots; ++s) {
-            // source block of every tile for this slot
-            size_t src[9];
+        unsigned src[9], srcn[9];
+        double bc[9], bn[9], ac[3], an[3];
+        load_src(0, src);
 #pragma unroll
-            for (int t = 0; t < GROUP; ++t) {
-                int n = atom[t] >= 0 ? P.nbr[(size_t)P.nslots * atom[t] + s] : -1;
-                if (n < 0) n = zero_block;
-                src[t] = (size_t)BLD * n + l15;                // column l15 of the atom-aligned tile
-            }
-            {
-                int n = my_rem_atom >= 0 ? P.nbr[(size_t)P.nslots * my_rem_atom + s] : -1;
-                if (n < 0) n = zero_block;
-                src[8] = (size_t)BLD * n + 16 + (l15 & 1);
-            }
+        for (int t = 0; t < 9; ++t) bc[t] = in[src[t] + koff[0]];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) ac[f] = fr[f * 64];
+
+        for (int s = 0; s < P.nslots; ++s) {
+            const int sn = (s + 1 < P.nslots) ? s + 1 : 0;    // last slot prefetches slot 0 again (discarded): no tail branch
+            load_src(sn, srcn);
             const double* fs = fr + (size_t)s * FRAG_PER_SLOT;
+            const double* fsn = fr + (size_t)sn * FRAG_PER_SLOT;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
-                const double a0 = fs[(q * 3 + 0) * 64], a1 = fs[(q * 3 + 1) * 64], a2 = fs[(q * 3 + 2) * 64];
-                const int kap = 4 * q + l4;                    // this lane's k-row: kappa = 18*part + r
-                const int koff = (kap < 18) ? 36 * kap : 36 * (kap - 18) + 18;
+                // prefetch the operands of the next k-step
+                if (q < 8) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) bn[t] = in[src[t] + koff[q + 1]];
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) an[f] = fs[((q + 1) * 3 + f) * 64];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) bn[t] = in[srcn[t] + koff[0]];
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) an[f] = fsn[f * 64];
+                }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const double b = in[src[t] + koff];
-                    acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, b, acc2[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[0], bc[t], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[1], bc[t], acc1[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ac[2], bc[t], acc2[t], 0, 0, 0);
                 }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bc[t] = bn[t];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) ac[f] = an[f];
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) src[t] = srcn[t];
         }
         // store: D layout row = l4 + 4*j (+16 for acc1), column = l15;  acc2: row 32 + l4
 #pragma unroll
@@ -156,6 +206,296 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_spmm(DevProblem P, Ch
             }
             ob[36 * (14 + l4) + 18] = acc2[t];                 // kappa = 32 + l4 -> part 1, r = 14 + l4
         }
+    }
+}
+
+
+// ======================================================================================================================
+// Post-hop kernels on the matrix cores.  In LayoutRM an atom block IS the real 18x36 matrix [X_re | X_im] (row-major), and
+//   * right-multiplication by a global complex 18x18 matrix G (psi*A_n, pmn*B^-1, psi*B; crecal_b :1927,:1966-1967) is
+//       [Y_re | Y_im] = [X_re | X_im] * Ghat,   Ghat = [[Gr, Gi], [-Gi, Gr]]   (36x36 real),
+//     i.e. a (18*natoms) x 36 x 36 GEMM: M = stacked rows (8 atoms = 144 rows = 9 tiles), K = 36, N = 36 = 16 + 16 + 4;
+//   * the 18x18 complex reductions  sum_i X_i^H Y_i  (A_n :1642, B^2 :1931) are the real 36x36 Gram matrices
+//       Gm[k'][k] = sum_rows Xhat[row][k'] * Yhat[row][k],   C_re = Gm[re,re] + Gm[im,im],  C_im = Gm[re,im] - Gm[im,re],
+//     with the stacked rows as the MFMA K dimension.  A 16x16x4 D register (rows l4+4j, column l15) is directly the operand
+//     fragment of k-step j, so freshly computed rows feed the Gram MFMAs without leaving registers.
+// ======================================================================================================================
+
+// Fragment table of a global 18x18 complex matrix G for right-multiplication: [9 q][3 f][64 lanes] doubles,
+//   f = 0,1 : B operand of the 16x16x4 MFMA, columns 16f + l15 ;  f = 2 : B operand of the 4x4x4 MFMA, columns 32 + (l & 3).
+__device__ __forceinline__ void emit_rhs_frags(const double2* M /*18x18 column-major, LDS or global*/, double sign, double* out) {
+    for (int e = threadIdx.x; e < 27 * 64; e += blockDim.x) {
+        const int l = e & 63, qf = e >> 6, q = qf / 3, f = qf % 3;
+        const int ki = 4 * q + (l >> 4);
+        const int ko = (f < 2) ? 16 * f + (l & 15) : 32 + (l & 3);
+        const int pi = ki / 18, ci = ki % 18, po = ko / 18, co = ko % 18;
+        const double2 g = M[ci + 18 * co];
+        double v = (pi == po) ? g.x : (pi == 0 ? g.y : -g.y);
+        out[e] = sign * v;
+    }
+}
+
+struct RowRef { unsigned off; bool valid; };
+__device__ __forceinline__ RowRef group_row(const int* __restrict__ grp, int rho, int zero_block) {
+    const int slot = rho / 18, r = rho - 18 * slot;
+    const int a = grp[slot];
+    RowRef R;
+    R.valid = a >= 0;
+    R.off = (unsigned)BLD * (unsigned)(R.valid ? a : zero_block) + 36u * (unsigned)r;
+    return R;
+}
+
+// ---- K3: psi_i <- pmn_i * Binv ; pmn_i <- psi_i * B  (crecal_b :1963-1969) --------------------------------------------
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_update(ChainView CV, int level, int zero_block, double* psi, double* pmn,
+                                                                 const double* __restrict__ bfrags /*[chain][2][27*64]: B, Binv*/) {
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain);
+    const size_t vo = (size_t)chain * CV.vstride;
+    double* ps = psi + vo;
+    double* pm = pmn + vo;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+    double gB[27], gBi[27];
+    {
+        const double* fb = bfrags + (size_t)chain * 2 * 27 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 27; ++e) { gB[e] = fb[e * 64]; gBi[e] = fb[(27 + e) * 64]; }
+    }
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
+#pragma unroll 1
+        for (int mt = 0; mt < 9; ++mt) {
+            const RowRef ra = group_row(grp, 16 * mt + l15, zero_block);           // A-operand row of this lane
+            double a1[9], a2[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { a1[q] = pm[ra.off + 4 * q + l4]; a2[q] = ps[ra.off + 4 * q + l4]; }
+            double4_t y1a = {0, 0, 0, 0}, y1b = {0, 0, 0, 0}, y2a = {0, 0, 0, 0}, y2b = {0, 0, 0, 0};
+            double y1r = 0.0, y2r = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                y1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], gBi[3 * q + 0], y1a, 0, 0, 0);
+                y1b = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], gBi[3 * q + 1], y1b, 0, 0, 0);
+                y1r = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[q], gBi[3 * q + 2], y1r, 0, 0, 0);
+                y2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 0], y2a, 0, 0, 0);
+                y2b = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 1], y2b, 0, 0, 0);
+                y2r = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[q], gB[3 * q + 2], y2r, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
+                if (rs.valid) {
+                    ps[rs.off + l15] = y1a[j]; ps[rs.off + 16 + l15] = y1b[j];
+                    pm[rs.off + l15] = y2a[j]; pm[rs.off + 16 + l15] = y2b[j];
+                }
+            }
+            const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);    // 4x4x4 D: row 4g + i, column 32 + j
+            if (rr.valid) { ps[rr.off + 32 + l3] = y1r; pm[rr.off + 32 + l3] = y2r; }
+        }
+    }
+}
+
+// canonical 36x36 (row-major) image of a wave's Gram accumulators, written to LDS and summed over the waves of a workgroup
+struct GramAcc {
+    double4_t t00, t01, t10, t11;   // 16x16 tiles (row tile, column tile)
+    double tr0, tr1;                // rows 32..35 x columns of tile 0 / 1   (4x4x4, blocks over N)
+    double t0r, t1r;                // rows of tile 0 / 1 x columns 32..35   (4x4x4, blocks over M)
+    double trr;                     // rows 32..35 x columns 32..35
+    __device__ __forceinline__ void zero() { t00 = t01 = t10 = t11 = (double4_t){0, 0, 0, 0}; tr0 = tr1 = t0r = t1r = trr = 0.0; }
+    __device__ __forceinline__ void to_lds(double* G /*[1296]*/, int lane, bool sym) const {
+        const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = l4 + 4 * j;
+            G[36 * r + l15] = t00[j];
+            G[36 * r + 16 + l15] = t01[j];
+            G[36 * (16 + r) + 16 + l15] = t11[j];
+            if (!sym) G[36 * (16 + r) + l15] = t10[j];
+        }
+        G[36 * (32 + l4) + l15] = tr0;
+        G[36 * (32 + l4) + 16 + l15] = tr1;
+        if (!sym) { G[36 * (4 * lg + l4) + 32 + l3] = t0r; G[36 * (16 + 4 * lg + l4) + 32 + l3] = t1r; }
+        if (lg == 0) G[36 * (32 + l4) + 32 + l3] = trr;
+    }
+};
+
+__device__ __forceinline__ void gram_block_out(const GramAcc& A, double* lds /*[MF_WAVES][1296]*/, double* gout /*[1296]*/, bool sym) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    A.to_lds(lds + wave * 1296, lane, sym);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1296; e += blockDim.x) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < MF_WAVES; ++wv) s += lds[wv * 1296 + e];
+        if (sym) {                                   // fill the tiles that were not computed from their transposes
+            const int r = e / 36, c = e % 36;
+            const bool have = (r >= 32) || (r < 16) || (c >= 16 && c < 32);
+            if (!have || (r < 32 && c >= 32)) {
+                double t = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < MF_WAVES; ++wv) t += lds[wv * 1296 + 36 * c + r];
+                s = t;
+            }
+        }
+        gout[e] = s;
+    }
+}
+
+// ---- A_n partial: Gm = sum_rows psihat^T * that   (hop_b :1642) -------------------------------------------------------
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, int level, int zero_block, const double* __restrict__ psi,
+                                                               const double* __restrict__ tvec, double* partial /*[chain][nblk][1296]*/) {
+    __shared__ double lds[MF_WAVES * 1296];
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain);
+    const size_t vo = (size_t)chain * CV.vstride;
+    const double* ps = psi + vo;
+    const double* tv = tvec + vo;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3;
+    GramAcc A;
+    A.zero();
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
+#pragma unroll 4
+        for (int kq = 0; kq < 36; ++kq) {
+            const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);               // k-row of this lane
+            const double p0 = ps[rk.off + l15], p1 = ps[rk.off + 16 + l15], pr = ps[rk.off + 32 + l3];
+            const double h0 = tv[rk.off + l15], h1 = tv[rk.off + 16 + l15], hr = tv[rk.off + 32 + l3];
+            A.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h0, A.t00, 0, 0, 0);
+            A.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h1, A.t01, 0, 0, 0);
+            A.t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, h0, A.t10, 0, 0, 0);
+            A.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, h1, A.t11, 0, 0, 0);
+            A.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, h0, A.tr0, 0, 0, 0);
+            A.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, h1, A.tr1, 0, 0, 0);
+            A.t0r = __builtin_amdgcn_mfma_f64_4x4x4f64(p0, hr, A.t0r, 0, 0, 0);
+            A.t1r = __builtin_amdgcn_mfma_f64_4x4x4f64(p1, hr, A.t1r, 0, 0, 0);
+            A.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, hr, A.trr, 0, 0, 0);
+        }
+    }
+    gram_block_out(A, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, false);
+}
+
+// ---- K2: pmn_i <- (t_i - pmn_i) - psi_i * A ; Gm += pmnhat^T pmnhat   (hop_b :1641, crecal_b :1922-1934) ----------------
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, int level, int zero_block, const double* __restrict__ psi, double* pmn,
+                                                               const double* __restrict__ tvec, const double* __restrict__ afrags /*[chain][27*64] = -A*/,
+                                                               double* partial /*[chain][nblk][1296]*/) {
+    __shared__ double lds[MF_WAVES * 1296];
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain);
+    const size_t vo = (size_t)chain * CV.vstride;
+    const double* ps = psi + vo;
+    const double* tv = tvec + vo;
+    double* pm = pmn + vo;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+    double nA[27];
+    {
+        const double* fa = afrags + (size_t)chain * 27 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 27; ++e) nA[e] = fa[e * 64];
+    }
+    GramAcc Gm;
+    Gm.zero();
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
+#pragma unroll 1
+        for (int mt = 0; mt < 9; ++mt) {
+            const RowRef ra = group_row(grp, 16 * mt + l15, zero_block);
+            double a[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) a[q] = ps[ra.off + 4 * q + l4];
+            // C = t - pmn in D layout
+            RowRef rs[4];
+            double4_t ca, cb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rs[j] = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
+                ca[j] = tv[rs[j].off + l15] - pm[rs[j].off + l15];
+                cb[j] = tv[rs[j].off + 16 + l15] - pm[rs[j].off + 16 + l15];
+            }
+            const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
+            double cr = tv[rr.off + 32 + l3] - pm[rr.off + 32 + l3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nA[3 * q + 0], ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nA[3 * q + 1], cb, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_4x4x4f64(a[q], nA[3 * q + 2], cr, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (rs[j].valid) { pm[rs[j].off + l15] = ca[j]; pm[rs[j].off + 16 + l15] = cb[j]; }
+            if (rr.valid) pm[rr.off + 32 + l3] = cr;
+            // Gram update: D register j = rows 4j..4j+3 of this tile = operand fragment of k-step j
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double f0 = ca[j], f1 = cb[j];
+                const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);   // Y[row 4j + l4][32 + l3], replicated over the 4 blocks
+                Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
+                Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
+                Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
+                Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
+                Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
+                Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
+            }
+        }
+    }
+    gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
+}
+
+// ---- reductions of the 36x36 real partials ----------------------------------------------------------------------------
+// returns C[cp + 18 c] (complex) for tid < 324:  C_re = G[re cp][re c] + G[im cp][im c],  C_im = G[re cp][im c] - G[im cp][re c]
+__device__ __forceinline__ double2 reduce_gram(const double* __restrict__ partial /*[nblk][1296]*/, int nblk, double* lds /*1296*/) {
+    for (int e = threadIdx.x; e < 1296; e += blockDim.x) {
+        double s = 0.0;
+        for (int p = 0; p < nblk; ++p) s += partial[(size_t)p * 1296 + e];
+        lds[e] = s;
+    }
+    __syncthreads();
+    double2 c = make_double2(0, 0);
+    if (threadIdx.x < BLK) {
+        const int cp = threadIdx.x % NB, cc = threadIdx.x / NB;
+        c.x = lds[36 * cp + cc] + lds[36 * (18 + cp) + 18 + cc];
+        c.y = lds[36 * cp + 18 + cc] - lds[36 * (18 + cp) + cc];
+    }
+    __syncthreads();
+    return c;
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_a_mf(const double* __restrict__ partial, int nblk, double2* a_out, size_t astride, double* afrags) {
+    __shared__ double lds[1296];
+    __shared__ double2 Am[BLK];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    if (threadIdx.x < BLK) { a_out[chain * astride + threadIdx.x] = c; Am[threadIdx.x] = c; }
+    __syncthreads();
+    emit_rhs_frags(Am, -1.0, afrags + (size_t)chain * 27 * 64);
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_b_eig_mf(const double* __restrict__ partial, int nblk, double2* b2_out, size_t bstride, double2* Bmats,
+                                                         double* bfrags, int* status) {
+    __shared__ double lds[1296];
+    __shared__ Eig18Shared sh;
+    __shared__ double2 Bm[BLK];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    if (threadIdx.x < BLK) { b2_out[chain * bstride + threadIdx.x] = c; sh.A[threadIdx.x] = c; }
+    __syncthreads();
+    const int sw = jacobi18(sh);
+    if (sw < 0 && threadIdx.x == 0) atomicOr(status, 1);
+    if (threadIdx.x < NB) { const double l = sqrt(sh.ev[threadIdx.x]); sh.f1[threadIdx.x] = l; sh.f2[threadIdx.x] = 1.0 / l; }
+    __syncthreads();
+    double2* Bout = Bmats + (size_t)chain * 2 * BLK;
+    for (int which = 0; which < 2; ++which) {
+        matfun18(sh, which ? sh.f2 : sh.f1, Bm);                                   // into LDS
+        __syncthreads();
+        for (int e = threadIdx.x; e < BLK; e += blockDim.x) Bout[which * BLK + e] = Bm[e];
+        emit_rhs_frags(Bm, 1.0, bfrags + ((size_t)chain * 2 + which) * 27 * 64);
+        __syncthreads();
     }
 }
 

@@ -43,13 +43,13 @@ struct DevProblem {
 };
 
 struct ChainView {           // per launch: a batch of chains with identical strides
-    const int* order;        // [nchain][kk]
+    const int* order;        // [nchain][ostride], entries < 0 are padding
     const int* cum;          // [nchain][nlev]
     int nlev;
     size_t vstride;          // doubles between chains in a work vector = (kk+1)*648 (last block is an all-zero block)
     int cpo;                 // chains sharing one order/cum row (1; 18 for the scalar recursion's orbital chains)
-    int kk;
-    __device__ __forceinline__ const int* order_of(int chain) const { return order + (size_t)(chain / cpo) * kk; }
+    int ostride;             // entries per order row (kk, or more when the list is padded into type-homogeneous groups of 8)
+    __device__ __forceinline__ const int* order_of(int chain) const { return order + (size_t)(chain / cpo) * ostride; }
     __device__ __forceinline__ int count_of(int chain, int level) const { return cum[(chain / cpo) * nlev + level]; }
 };
 

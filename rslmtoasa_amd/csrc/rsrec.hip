@@ -61,12 +61,13 @@ struct rsrec_handle {
     DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
     MfmaOperator mfma_op;
     // work
-    DevBuf d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
+    DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
+    int hop_fuses_a = 1;      // 1: the timed H|psi> kernel also forms pmn and the A_n partial (VALU path); 0: pure SpMM (MFMA path)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
 };
@@ -161,7 +162,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->d_nbr, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
-                     &h->d_status, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
+                     &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
     h->mfma_op.release();
     (void)hipStreamDestroy(h->stream);
@@ -180,14 +181,16 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     if (!strcmp(key, "batch")) h->opt_batch = value;
     else if (!strcmp(key, "kernels")) h->opt_kernels = value;
     else if (!strcmp(key, "nblk")) h->opt_nblk = value;
+    else if (!strcmp(key, "wps")) h->opt_wps = value;
+    else if (!strcmp(key, "post")) h->opt_post = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
 
 extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
     if (!h || !out) return RSREC_ERR_ARG;
-    const double v[7] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms};
-    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+    const double v[8] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
     return RSREC_OK;
 }
 
@@ -332,16 +335,39 @@ int plan_batch(rsrec_t* h, int nchains, int nvec, size_t vec_elems_per_chain, Ba
 }
 
 // Upload the regions of one batch. seeds: [nb][nseed] 0-based.
-int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, int napply, bool two_pass, double& atom_steps, double& block_mults) {
+// grouped = true: every BFS level is sorted by operator class tau (per-atom blocks first, then types) and each class run is
+// padded with -1 to a multiple of GROUP, so that 8 consecutive entries always share their operator blocks (MFMA kernels).
+int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, int napply, bool two_pass, bool grouped, int& ostride,
+                   double& atom_steps, double& block_mults) {
     const int kk = h->kk;
-    std::vector<int> order((size_t)nb * kk), cum((size_t)nb * nlev);
+    ostride = grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk;
+    std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)nb * nlev);
     std::vector<double> as(nb, 0.0), bm(nb, 0.0);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int c = 0; c < nb; ++c) {
         Region R;
         grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, R);
-        std::copy(R.order.begin(), R.order.end(), order.begin() + (size_t)c * kk);
-        std::copy(R.cum.begin(), R.cum.end(), cum.begin() + (size_t)c * nlev);
+        int* orow = order.data() + (size_t)c * ostride;
+        int* crow = cum.data() + (size_t)c * nlev;
+        if (!grouped) {
+            std::copy(R.order.begin(), R.order.end(), orow);
+            std::copy(R.cum.begin(), R.cum.end(), crow);
+        } else {
+            auto tau = [&](int i) { return i < h->nmax ? i : h->nmax + h->iz0[i]; };
+            int w = 0;
+            std::vector<int> lev;
+            for (int L = 0; L < nlev; ++L) {
+                const int lo = L ? R.cum[L - 1] : 0, hi = R.cum[L];
+                lev.assign(R.order.begin() + lo, R.order.begin() + hi);
+                std::stable_sort(lev.begin(), lev.end(), [&](int x, int y) { return tau(x) < tau(y); });
+                for (size_t q = 0; q < lev.size(); ++q) {
+                    if (q > 0 && tau(lev[q]) != tau(lev[q - 1])) while (w % GROUP) orow[w++] = -1;
+                    orow[w++] = lev[q];
+                }
+                while (w % GROUP) orow[w++] = -1;
+                crow[L] = w;
+            }
+        }
         // bookkeeping in the reference's terms: application t (1..napply) multiplies one block per (atom, slot) whose
         // source atom lies in the region before it; post-hop work runs on the region after it.
         double a_s = 0.0, b_m = 0.0;
@@ -350,8 +376,6 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             a_s += R.cum[std::min(lv_after, nlev - 1)];
             if (two_pass) b_m += 2.0 * R.cum[2 * (t - 1)];   // enim*psi and lsham*psi on-site products (hop_b_hoh :1437-1438)
         }
-        // count products: for each atom n at distance d, it is a source in applications with region-before containing it
-        // region before application t = level (t-1) [one pass] ; two passes: pass1 before-level 2(t-1), pass2 before-level 2t-1
         std::vector<int> lev_of(kk, -1);
         {
             int lv = 0;
@@ -406,29 +430,24 @@ int check_ready(rsrec_t* h, const char* who) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld,
-                                          double* a_b, double* b2_b) {
-    int rc = check_ready(h, "rsrec_block_lanczos");
-    if (rc) return rc;
-    if (nchains < 0 || nseed < 1 || lld < 1 || !a_b || !b2_b || (nchains > 0 && !seed_atoms)) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: bad argument");
-    for (int q = 0; q < nchains * nseed; ++q)
-        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
-    HIPCK(h, hipSetDevice(h->device));
-    reset_timing(h);
-    if (nchains == 0) return RSREC_OK;
+namespace {
+
+// One implementation for both kernel sets: L = LayoutCM with the VALU kernels, LayoutRM with the MFMA SpMM.
+template <class L, bool MFMA>
+int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld, double* a_b, double* b2_b) {
     const int kk = h->kk;
     const bool hoh = h->hoh != 0;
-    const bool use_mfma = (h->opt_kernels == 2);
     const int nsteps = lld - 1;
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
-    const size_t velems = (size_t)kk * BLK;                 // double2 per chain per vector
-    const int nvec = hoh ? 3 : 2;
+    const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
+    const int nvec = (hoh || MFMA) ? 3 : 2;
     BatchPlan bp;
-    rc = plan_batch(h, nchains, nvec, velems, bp);
+    int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
-    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double2)));
-    HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
+    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
+    HIPCK(h, h->d_partial.reserve((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_frags.reserve((size_t)B * 3 * 27 * 64 * sizeof(double)));
     HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_bmats.reserve((size_t)B * 2 * BLK * sizeof(double2)));
@@ -436,20 +455,23 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)B * nseed * sizeof(double2)));
     HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
-    double2* psi = h->d_vec[0].as<double2>();
-    double2* pmn = h->d_vec[1].as<double2>();
-    double2* hpsi = h->d_vec[2].as<double2>();
+    double* psi = h->d_vec[0].as<double>();
+    double* pmn = h->d_vec[1].as<double>();
+    double* hpsi = h->d_vec[2].as<double>();
     double2* dA = h->d_coefA.as<double2>();
     double2* dB = h->d_coefB.as<double2>();
+    double2* partial = h->d_partial.as<double2>();
+    double* gpartial = h->d_partial.as<double>();
+    double* afrags = h->d_frags.as<double>();
+    double* bfrags = afrags + (size_t)B * 27 * 64;
+    const bool mf_post = MFMA && h->opt_post != 1;
     const DevProblem P = make_problem(h);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_orth), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ATOMS * BLK * (int)sizeof(double2)));
-        attr_set = true;
-    }
+    HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_orth<L>), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ATOMS * BLK * (int)sizeof(double2)));
     const size_t cstride = (size_t)lld * BLK;
+    const size_t orth_lds = TILE_ATOMS * BLK * sizeof(double2);
     hipEvent_t ev_begin = next_event(h);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
+    h->hop_fuses_a = MFMA ? 0 : 1;
 
     for (int c0 = 0; c0 < nchains; c0 += B) {
         const int nb = std::min(B, nchains - c0);
@@ -461,7 +483,8 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
             coef[2 * q] = seed_coef ? seed_coef[2 * ((size_t)c0 * nseed + q)] : 1.0;
             coef[2 * q + 1] = seed_coef ? seed_coef[2 * ((size_t)c0 * nseed + q) + 1] : 0.0;
         }
-        rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, nsteps, hoh, h->n_atom_steps, h->n_block_mult);
+        int ostride = kk;
+        rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, nsteps, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -469,35 +492,58 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
 
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.kk = kk;
-        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double2), h->stream));
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
-        k_seed<<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
         const dim3 grid(nblk, nb);
+        const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
             const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
+            const double* tvec = nullptr;                      // H psi when it is held in a vector of its own
             hipEvent_t e0 = next_event(h);
+            hipEvent_t e1 = nullptr;
             ApplyArgs G{};
-            G.partial = h->d_partial.as<double2>();
+            G.partial = partial;
             if (!hoh) {
-                G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                if (use_mfma) launch_hop_mfma(h->mfma_op, P, CV, G, grid, h->stream);
-                else k_apply<AM_LANCZOS><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                if (MFMA) {
+                    SpmmArgs S{h->mfma_op.set_ptr(0), psi, hpsi, lv_final};
+                    if (h->opt_wps == 2) k_mfma_spmm<2><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(P, CV, S);
+                    else k_mfma_spmm<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(P, CV, S);
+                    e1 = next_event(h);
+                    tvec = hpsi;
+                    if (mf_post) {
+                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                        k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
+                        k_mfma_orth<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
+                        k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                       h->d_status.as<int>());
+                        k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                        hop_ev.emplace_back(e0, e1);
+                        h->n_hop_launch += 1;
+                        continue;
+                    }
+                    k_adot<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, hpsi, partial);
+                } else {
+                    G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                    k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    e1 = next_event(h);
+                }
             } else {
                 G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
-                k_apply<AM_STORE><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 G.in = hpsi; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                k_apply<AM_HOH_LANCZOS><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                k_apply<AM_HOH_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                e1 = next_event(h);
             }
-            hipEvent_t e1 = next_event(h);                     // [e0,e1] brackets exactly the H|psi> kernel(s) of this step
-            hop_ev.emplace_back(e0, e1);
+            hop_ev.emplace_back(e0, e1);                       // [e0,e1] brackets exactly the H|psi> kernel(s) of this step
             h->n_hop_launch += hoh ? 2 : 1;
-            k_reduce_a<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dA + (size_t)ll * BLK, cstride);
-            k_orth<<<grid, NTHREADS, TILE_ATOMS * BLK * sizeof(double2), h->stream>>>(kk, CV, lv_final, psi, pmn, dA + (size_t)ll * BLK, cstride, h->d_partial.as<double2>());
-            k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
-            k_update<<<grid, NTHREADS, 0, h->stream>>>(kk, CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
+            k_reduce_a<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride);
+            k_orth<L><<<grid, NTHREADS, orth_lds, h->stream>>>(CV, lv_final, psi, pmn, tvec, dA + (size_t)ll * BLK, cstride, partial);
+            k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(partial, nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
+            k_update<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
         }
         HIPCK(h, hipGetLastError());
         HIPCK(h, hipMemcpyAsync(a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
@@ -513,6 +559,24 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
     HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
     if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
     return RSREC_OK;
+}
+
+}  // namespace
+
+extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld,
+                                          double* a_b, double* b2_b) {
+    int rc = check_ready(h, "rsrec_block_lanczos");
+    if (rc) return rc;
+    if (nchains < 0 || nseed < 1 || lld < 1 || !a_b || !b2_b || (nchains > 0 && !seed_atoms)) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: bad argument");
+    for (int q = 0; q < nchains * nseed; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nchains == 0) return RSREC_OK;
+    // kernels: 0 = auto (MFMA where implemented), 1 = VALU reference kernels, 2 = MFMA
+    const bool use_mfma = (h->opt_kernels != 1) && !h->hoh;
+    if (use_mfma) return run_block_lanczos<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
+    return run_block_lanczos<LayoutCM, false>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
 }
 
 extern "C" int rsrec_block_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double* a_b, double* b2_b) {
@@ -552,13 +616,13 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
     const int napply = lld + 1;                                  // first moment + lld steps
     const int nlev = (hoh ? 2 * napply : napply) + 1;
     const int nmom = 2 * lld + 2;
-    const size_t velems = (size_t)kk * BLK;
+    const size_t velems = (size_t)(kk + 1) * BLD;
     const int nvec = hoh ? 4 : 3;
     BatchPlan bp;
-    rc = plan_batch(h, nsites, nvec, velems, bp);
+    rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
-    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double2)));
+    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
@@ -576,21 +640,22 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
         std::vector<int> seeds0(nb);
         std::vector<double> coef((size_t)nb * 2);
         for (int q = 0; q < nb; ++q) { seeds0[q] = seed_atoms[c0 + q] - 1; coef[2 * q] = 1.0; coef[2 * q + 1] = 0.0; }
-        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, h->n_atom_steps, h->n_block_mult);
+        int ostride = kk;
+        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, false, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.kk = kk;
-        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double2), h->stream));
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
-        double2* p0 = h->d_vec[0].as<double2>();
-        double2* p1 = h->d_vec[1].as<double2>();
-        double2* p2 = h->d_vec[2].as<double2>();
-        double2* tmp = h->d_vec[3].as<double2>();
-        k_seed<<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
+        double* p0 = h->d_vec[0].as<double>();
+        double* p1 = h->d_vec[1].as<double>();
+        double* p2 = h->d_vec[2].as<double>();
+        double* tmp = h->d_vec[3].as<double>();
+        k_seed<LayoutCM><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
         k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride);                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
@@ -600,24 +665,24 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
             ApplyArgs G{};
             G.partial = h->d_partial.as<double2>();
             G.a = a; G.b = b;
-            double2* src = first ? p0 : p1;
-            double2* dst = first ? p1 : p2;
+            double* src = first ? p0 : p1;
+            double* dst = first ? p1 : p2;
             if (!hoh) {
                 G.in = src; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
-                if (first) k_apply<AM_CHEB1><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                else k_apply<AM_CHEBN><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                if (first) k_apply<AM_CHEB1, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_CHEBN, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             } else {
                 G.in = src; G.out = tmp; G.level = 2 * t - 1;
-                k_apply<AM_STORE><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                k_apply<AM_STORE, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 G.in = tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
-                if (first) k_apply<AM_HOH_CHEB1><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                else k_apply<AM_HOH_CHEBN><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                if (first) k_apply<AM_HOH_CHEB1, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_HOH_CHEBN, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             }
             hipEvent_t e1 = next_event(h);
             hop_ev.emplace_back(e0, e1);
             h->n_hop_launch += hoh ? 2 : 1;
             k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>());
-            if (!first) { double2* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
+            if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
         }
         HIPCK(h, hipGetLastError());
         HIPCK(h, hipMemcpyAsync(mu_n + (size_t)c0 * mstride * 2, mu, (size_t)nb * mstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
@@ -681,13 +746,14 @@ extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_
             for (int l = 0; l < NB; ++l) { so[2 * (q * NB + l)] = seeds0[q]; so[2 * (q * NB + l) + 1] = l; }
         }
         double dummy1 = 0, dummy2 = 0;
-        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, nsteps, false, dummy1, dummy2);
+        int ostride = kk;
+        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, nsteps, false, false, ostride, dummy1, dummy2);
         if (rc) return rc;
         h->n_atom_steps += dummy1 * NB;
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.kk = kk;
+        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
         for (int v = 0; v < 2; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nc * velems * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(ca, 0, (size_t)nch * 2 * lld * sizeof(double), h->stream));
         k_scalar_seed<<<nc, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), cb, lld);

@@ -67,6 +67,8 @@ def supercell(name, kernels, nsites=1):
     ham, lat, ctl, en = objects_from(p, sites, int(g["lld"]), emin=float(g["emin"]), emax=float(g["emax"]))
     rec = Recursion(ham, lat, ctl, en)
     rec.set_option("kernels", kernels)
+    if os.environ.get("RSREC_WPS"):
+        rec.set_option("wps", int(os.environ["RSREC_WPS"]))
     if int(g["kind"]) == 0:
         rec.recur_b()
         n = len(g["irec"])
@@ -83,6 +85,12 @@ def supercell(name, kernels, nsites=1):
 
 
 if __name__ == "__main__":
+    if os.environ.get("RSREC_ONLY_SC"):
+        for k in [int(x) for x in os.environ.get("RSREC_KERNELS", "2").split(",")]:
+            run("supercell sc_22_block k=%d" % k, lambda: supercell("sc_22_block", k))
+            run("supercell sc_22_block k=%d x16 sites" % k, lambda: supercell("sc_22_block", k, 16))
+            run("supercell sc_22_block k=%d x64 sites" % k, lambda: supercell("sc_22_block", k, 64))
+        sys.exit(0)
     ks = [int(x) for x in os.environ.get("RSREC_KERNELS", "1").split(",")]
     for k in ks:
         for name in BLOCK_CASES:
