@@ -105,111 +105,6 @@ struct GroupWalk {
 // out_i = sum_slots H_slot * in_{nbr(i,slot)} for every atom of the (padded, type-homogeneous) order prefix.
 // One wave = one group of 8 atoms.  Group entries < 0 are padding.  Operand fragments are software-pipelined one k-step
 // ahead in registers (hipcc otherwise waits for every load right before its three MFMAs).
-template <int WPS>
-__global__ __launch_bounds__(MF_WAVES * 64, WPS) void k_mfma_spmm(DevProblem P, ChainView CV, SpmmArgs G) {
-    const int chain = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: group bookkeeping lives in SGPRs
-    const int count = CV.count_of(chain, G.level);          // multiple of GROUP
-    const int ngroups = count / GROUP;
-    const int* order = CV.order_of(chain);
-    const size_t vo = (size_t)chain * CV.vstride;
-    const double* __restrict__ in = G.in + vo;
-    double* out = G.out + vo;
-    const int zero_block = P.kk;                              // index of the all-zero block (absent neighbours, padding)
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // per-lane element offset of k-row (4q + l4) inside a block: kappa = 18*part + r -> 36 r + 18 part
-    int koff[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { const int kap = 4 * q + l4; koff[q] = (kap < 18) ? 36 * kap : 36 * (kap - 18) + 18; }
-
-    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
-        const int* grp = order + (size_t)w.g * GROUP;
-        int atom[GROUP];
-#pragma unroll
-        for (int t = 0; t < GROUP; ++t) atom[t] = grp[t];
-        const int first = atom[0];                             // groups are never empty: entry 0 is a real atom
-        const int tau = first < P.nmax ? first : P.nmax + P.iz[first];
-        const int my_rem_atom = grp[l15 >> 1];                 // remainder tile: lane -> (atom (l15>>1), column 16 + (l15&1))
-        const double* fr = G.frag + (size_t)tau * P.nslots * FRAG_PER_SLOT + lane;
-
-        auto load_src = [&](int s, unsigned (&src)[9]) {
-#pragma unroll
-            for (int t = 0; t < GROUP; ++t) {
-                int n = atom[t] >= 0 ? P.nbr[(size_t)P.nslots * atom[t] + s] : -1;
-                if (n < 0) n = zero_block;
-                src[t] = (unsigned)BLD * n + l15;              // column l15 of the atom-aligned tile
-            }
-            int n = my_rem_atom >= 0 ? P.nbr[(size_t)P.nslots * my_rem_atom + s] : -1;
-            if (n < 0) n = zero_block;
-            src[8] = (unsigned)BLD * n + 16 + (l15 & 1);
-        };
-
-        double4_t acc0[9], acc1[9];
-        double acc2[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) { acc0[t] = (double4_t){0, 0, 0, 0}; acc1[t] = (double4_t){0, 0, 0, 0}; acc2[t] = 0.0; }
-
-        unsigned src[9], srcn[9];
-        double bc[9], bn[9], ac[3], an[3];
-        load_src(0, src);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) bc[t] = in[src[t] + koff[0]];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) ac[f] = fr[f * 64];
-
-        for (int s = 0; s < P.nslots; ++s) {
-            const int sn = (s + 1 < P.nslots) ? s + 1 : 0;    // last slot prefetches slot 0 again (discarded): no tail branch
-            load_src(sn, srcn);
-            const double* fs = fr + (size_t)s * FRAG_PER_SLOT;
-            const double* fsn = fr + (size_t)sn * FRAG_PER_SLOT;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                // prefetch the operands of the next k-step
-                if (q < 8) {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) bn[t] = in[src[t] + koff[q + 1]];
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) an[f] = fs[((q + 1) * 3 + f) * 64];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) bn[t] = in[srcn[t] + koff[0]];
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) an[f] = fsn[f * 64];
-                }
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[0], bc[t], acc0[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[1], bc[t], acc1[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ac[2], bc[t], acc2[t], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < 9; ++t) bc[t] = bn[t];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) ac[f] = an[f];
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) src[t] = srcn[t];
-        }
-        // store: D layout row = l4 + 4*j (+16 for acc1), column = l15;  acc2: row 32 + l4
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int a = (t < 8) ? atom[t] : my_rem_atom;
-            if (a < 0) continue;
-            double* ob = out + (size_t)BLD * a + ((t < 8) ? l15 : 16 + (l15 & 1));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k0 = l4 + 4 * j;                     // 0..15 -> part 0, r = k0
-                ob[36 * k0] = acc0[t][j];
-                const int k1 = 16 + l4 + 4 * j;                // 16..31
-                ob[(k1 < 18) ? 36 * k1 : 36 * (k1 - 18) + 18] = acc1[t][j];
-            }
-            ob[36 * (14 + l4) + 18] = acc2[t];                 // kappa = 32 + l4 -> part 1, r = 14 + l4
-        }
-    }
-}
-
-
 // ======================================================================================================================
 // Post-hop kernels on the matrix cores.  In LayoutRM an atom block IS the real 18x36 matrix [X_re | X_im] (row-major), and
 //   * right-multiplication by a global complex 18x18 matrix G (psi*A_n, pmn*B^-1, psi*B; crecal_b :1927,:1966-1967) is
@@ -379,6 +274,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
 }
 
 // ---- K2: pmn_i <- (t_i - pmn_i) - psi_i * A ; Gm += pmnhat^T pmnhat   (hop_b :1641, crecal_b :1922-1934) ----------------
+template <bool HAS_T>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, int level, int zero_block, const double* __restrict__ psi, double* pmn,
                                                                const double* __restrict__ tvec, const double* __restrict__ afrags /*[chain][27*64] = -A*/,
                                                                double* partial /*[chain][nblk][1296]*/) {
@@ -390,7 +286,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
     const int* order = CV.order_of(chain);
     const size_t vo = (size_t)chain * CV.vstride;
     const double* ps = psi + vo;
-    const double* tv = tvec + vo;
+    const double* tv = HAS_T ? tvec + vo : nullptr;
     double* pm = pmn + vo;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     double nA[27];
@@ -415,11 +311,16 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 rs[j] = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
-                ca[j] = tv[rs[j].off + l15] - pm[rs[j].off + l15];
-                cb[j] = tv[rs[j].off + 16 + l15] - pm[rs[j].off + 16 + l15];
+                if (HAS_T) {
+                    ca[j] = tv[rs[j].off + l15] - pm[rs[j].off + l15];
+                    cb[j] = tv[rs[j].off + 16 + l15] - pm[rs[j].off + 16 + l15];
+                } else {
+                    ca[j] = pm[rs[j].off + l15];
+                    cb[j] = pm[rs[j].off + 16 + l15];
+                }
             }
             const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
-            double cr = tv[rr.off + 32 + l3] - pm[rr.off + 32 + l3];
+            double cr = HAS_T ? tv[rr.off + 32 + l3] - pm[rr.off + 32 + l3] : pm[rr.off + 32 + l3];
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nA[3 * q + 0], ca, 0, 0, 0);
@@ -445,6 +346,185 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
         }
     }
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
+}
+
+struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; };
+
+// All pointers are separate __restrict__ kernel parameters: only `out` is written, so hipcc can prove the index tables
+// read-only and fetch them with scalar loads (they then never enter the vmcnt queue the operand prefetch relies on).
+// FUSE = false: out_i = sum_slots H_slot in_nbr (store mode).
+// FUSE = true : the whole hop_b (recursion.f90:1560-1648): out holds pmn and becomes  H psi - pmn ; the A_n partial
+//               sum_i psi_i^H (H psi)_i is formed from the accumulators through a wave-private LDS transpose, so H psi never
+//               goes to HBM.  `partial` receives one 36x36 real Gram image per workgroup.
+template <int WPS, bool FUSE>
+__global__ __launch_bounds__(MF_WAVES * 64, WPS) void k_mfma_spmm(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
+                                                                 const int* __restrict__ nbr, const int* __restrict__ izp,
+                                                                 const double* __restrict__ frag, const double* __restrict__ in_all,
+                                                                 double* __restrict__ out_all, double* __restrict__ partial) {
+    __shared__ double lds[FUSE ? MF_WAVES * 1296 : 1];
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: group bookkeeping lives in SGPRs
+    const int count = cum[(chain / D.cpo) * D.nlev + D.level];           // multiple of GROUP
+    const int ngroups = count / GROUP;
+    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride;
+    const size_t vo = (size_t)chain * D.vstride;
+    const double* __restrict__ in = in_all + vo;
+    double* __restrict__ out = out_all + vo;
+    struct { int kk, nslots, nmax; } P = {D.kk, D.nslots, D.nmax};
+    const int zero_block = P.kk;                              // index of the all-zero block (absent neighbours, padding)
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3;
+    GramAcc Gm;
+    Gm.zero();
+    // per-lane element offset of k-row (4q + l4) inside a block: kappa = 18*part + r -> 36 r + 18 part
+    int koff[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const int kap = 4 * q + l4; koff[q] = (kap < 18) ? 36 * kap : 36 * (kap - 18) + 18; }
+
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* __restrict__ grp = order + (size_t)w.g * GROUP;
+        int atom[GROUP];
+#pragma unroll
+        for (int t = 0; t < GROUP; ++t) atom[t] = grp[t];
+        const int first = atom[0];                             // groups are never empty: entry 0 is a real atom
+        const int tau = first < P.nmax ? first : P.nmax + izp[first];
+        const int my_rem_atom = grp[l15 >> 1];                 // remainder tile: lane -> (atom (l15>>1), column 16 + (l15&1))
+        const double* __restrict__ fr = frag + (size_t)tau * P.nslots * FRAG_PER_SLOT + lane;
+
+        auto load_src = [&](int s, unsigned (&src)[9]) {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                int n = atom[t] >= 0 ? nbr[(size_t)P.nslots * atom[t] + s] : -1;
+                if (n < 0) n = zero_block;
+                src[t] = (unsigned)BLD * n + l15;              // column l15 of the atom-aligned tile
+            }
+            int n = my_rem_atom >= 0 ? nbr[(size_t)P.nslots * my_rem_atom + s] : -1;
+            if (n < 0) n = zero_block;
+            src[8] = (unsigned)BLD * n + 16 + (l15 & 1);
+        };
+
+        double4_t acc0[9], acc1[9];
+        double acc2[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { acc0[t] = (double4_t){0, 0, 0, 0}; acc1[t] = (double4_t){0, 0, 0, 0}; acc2[t] = 0.0; }
+
+        // Operand ring: three buffers, loads issued TWO k-steps ahead of their MFMAs.  9 k-steps per slot = 3 x 3, so the
+        // buffer a k-step uses is the same in every slot and no register copies are needed.
+        unsigned src[9], srcn[9];
+        double bq[3][9], aq[3][3];
+        load_src(0, src);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bq[p][t] = in[src[t] + koff[p]];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) aq[p][f] = fr[(p * 3 + f) * 64];
+        }
+
+        for (int s = 0; s < P.nslots; ++s) {
+            const int sn = (s + 1 < P.nslots) ? s + 1 : 0;    // last slot prefetches slot 0 again (discarded): no tail branch
+            load_src(sn, srcn);
+            const double* fs = fr + (size_t)s * FRAG_PER_SLOT;
+            const double* fsn = fr + (size_t)sn * FRAG_PER_SLOT;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int cur = q % 3, nxt = (q + 2) % 3;
+                if (q + 2 < 9) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) bq[nxt][t] = in[src[t] + koff[q + 2]];
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) aq[nxt][f] = fs[((q + 2) * 3 + f) * 64];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) bq[nxt][t] = in[srcn[t] + koff[q + 2 - 9]];
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) aq[nxt][f] = fsn[((q + 2 - 9) * 3 + f) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ABOVE this k-step's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[cur][0], bq[cur][t], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[cur][1], bq[cur][t], acc1[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[cur][2], bq[cur][t], acc2[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) src[t] = srcn[t];
+        }
+        // epilogue.  D layout: acc0/acc1 row kappa = l4 + 4j (+16), column = l15 ;  acc2: row 32 + l4.
+        // kappa = 18*part + r  ->  element offset 36 r + 18 part inside the block.
+        int ro0[4], ro1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ro0[j] = 36 * (l4 + 4 * j);
+            const int k1 = 16 + l4 + 4 * j;
+            ro1[j] = (k1 < 18) ? 36 * k1 : 36 * (k1 - 18) + 18;
+        }
+        const int ro2 = 36 * (14 + l4) + 18;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int a = (t < 8) ? atom[t] : my_rem_atom;
+            if (a < 0) continue;
+            double* ob = out + (size_t)BLD * a + ((t < 8) ? l15 : 16 + (l15 & 1));
+            if (FUSE) {                                        // pmn <- H psi - pmn   (hop_b :1641)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ob[ro0[j]] = acc0[t][j] - ob[ro0[j]]; ob[ro1[j]] = acc1[t][j] - ob[ro1[j]]; }
+                ob[ro2] = acc2[t] - ob[ro2];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ob[ro0[j]] = acc0[t][j]; ob[ro1[j]] = acc1[t][j]; }
+                ob[ro2] = acc2[t];
+            }
+        }
+        if (FUSE) {
+            // A_n partial: two atoms at a time, H psi goes through this wave's LDS slab (2 blocks in LayoutRM) so that the
+            // stacked rows (atom, r) become the MFMA K dimension.
+            double* hw = lds + wave * 1296;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 2 * pr + u;
+                    double* hb = hw + u * BLD + l15;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hb[ro0[j]] = acc0[t][j]; hb[ro1[j]] = acc1[t][j]; }
+                    hb[ro2] = acc2[t];
+                }
+                if ((l15 >> 2) == pr) {                        // remainder tile: lanes of atoms 2pr, 2pr+1
+                    double* hb = hw + ((l15 >> 1) & 1) * BLD + 16 + (l15 & 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hb[ro0[j]] = acc0[8][j]; hb[ro1[j]] = acc1[8][j]; }
+                    hb[ro2] = acc2[8];
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int kq = 0; kq < 9; ++kq) {
+                    const int rho = 4 * kq + l4;               // stacked row: atom (2pr + rho/18), row rho%18
+                    const int which = rho >= 18 ? 1 : 0, r = rho - 18 * which;
+                    int a = which ? atom[2 * pr + 1] : atom[2 * pr];
+                    if (a < 0) a = zero_block;
+                    const double* pb = in + (size_t)BLD * a + 36 * r;
+                    const double* hb = hw + which * BLD + 36 * r;
+                    const double p0 = pb[l15], p1 = pb[16 + l15], pq = pb[32 + l3];
+                    const double h0 = hb[l15], h1 = hb[16 + l15], hq = hb[32 + l3];
+                    Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h0, Gm.t00, 0, 0, 0);
+                    Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h1, Gm.t01, 0, 0, 0);
+                    Gm.t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, h0, Gm.t10, 0, 0, 0);
+                    Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, h1, Gm.t11, 0, 0, 0);
+                    Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pq, h0, Gm.tr0, 0, 0, 0);
+                    Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pq, h1, Gm.tr1, 0, 0, 0);
+                    Gm.t0r = __builtin_amdgcn_mfma_f64_4x4x4f64(p0, hq, Gm.t0r, 0, 0, 0);
+                    Gm.t1r = __builtin_amdgcn_mfma_f64_4x4x4f64(p1, hq, Gm.t1r, 0, 0, 0);
+                    Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(pq, hq, Gm.trr, 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (FUSE) {
+        __syncthreads();
+        gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, false);
+    }
 }
 
 // ---- reductions of the 36x36 real partials ----------------------------------------------------------------------------

@@ -63,7 +63,7 @@ struct rsrec_handle {
     // work
     DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_fuse = 0;   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -183,6 +183,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "nblk")) h->opt_nblk = value;
     else if (!strcmp(key, "wps")) h->opt_wps = value;
     else if (!strcmp(key, "post")) h->opt_post = value;
+    else if (!strcmp(key, "fuse")) h->opt_fuse = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -471,7 +472,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const size_t orth_lds = TILE_ATOMS * BLK * sizeof(double2);
     hipEvent_t ev_begin = next_event(h);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
-    h->hop_fuses_a = MFMA ? 0 : 1;
+    h->hop_fuses_a = (MFMA && !(h->opt_post != 1 && h->opt_fuse)) ? 0 : 1;
 
     for (int c0 = 0; c0 < nchains; c0 += B) {
         const int nb = std::min(B, nchains - c0);
@@ -509,15 +510,30 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             G.partial = partial;
             if (!hoh) {
                 if (MFMA) {
-                    SpmmArgs S{h->mfma_op.set_ptr(0), psi, hpsi, lv_final};
-                    if (h->opt_wps == 2) k_mfma_spmm<2><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(P, CV, S);
-                    else k_mfma_spmm<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(P, CV, S);
+                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems};
+                    const double* frag = h->mfma_op.set_ptr(0);
+                    if (mf_post && h->opt_fuse) {
+                        // fused hop_b: pmn <- H psi - pmn and the A_n partial inside the SpMM kernel
+                        if (h->opt_wps == 2) k_mfma_spmm<2, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, pmn, gpartial);
+                        else k_mfma_spmm<1, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, pmn, gpartial);
+                        e1 = next_event(h);
+                        k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
+                        k_mfma_orth<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
+                        k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                       h->d_status.as<int>());
+                        k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                        hop_ev.emplace_back(e0, e1);
+                        h->n_hop_launch += 1;
+                        continue;
+                    }
+                    if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
+                    else k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
                     e1 = next_event(h);
                     tvec = hpsi;
                     if (mf_post) {
                         k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
-                        k_mfma_orth<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
+                        k_mfma_orth<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
                         k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                        h->d_status.as<int>());
                         k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
