@@ -1,0 +1,308 @@
+!------------------------------------------------------------------------------
+! recursion_gpu_mod -- MI355X drop-in for the recursion drivers of RS-LMTO-ASA.
+!
+! `type(recursion_gpu)` EXTENDS the reference's `type(recursion)` (source/recursion.f90:41-116) and overrides
+! exactly the hot-path type-bound procedures
+!     recur_b (:1807)   recur_b_ij (:1655)   chebyshev_recur (:3057)   recur (:3485)   zsqr (:1980)
+! with calls into librsrec (hand-written HIP kernels behind the C ABI of include/rsrec.h).  Everything else --
+! data members a, b2, a_b, b2_b, mu_n (same shapes, same index order), the terminator routines get_terminf / bpopt /
+! emami used by green.f90 and density_of_states.f90, restore_to_default -- is inherited unchanged, and every consumer
+! in the reference holds a `class(recursion), pointer` (self.f90:64, green.f90:45, density_of_states.f90:44,
+! bands.f90:61), so the SCF loop dispatches to the GPU drivers without being edited.  The only edit a maintainer makes
+! is the declaration/constructor in calculation.f90 (see INTEGRATION.md):
+!     type(recursion_gpu), target :: recursion_obj ;  recursion_obj = recursion_gpu(hamiltonian_obj, energy_obj)
+!
+! Device context: ONE module-level handle per process, created lazily on the first driver call.  Nothing device-side
+! lives in the type, so the reference's "construct by intrinsic assignment from a function result + final ::
+! destructor" pattern (calculation.f90:599, recursion.f90:115,150) cannot leave a dangling handle.
+! MPI rank r uses GPU mod(r, device_count); sites are split by the reference's own get_mpi_variables (mpi.f90:32).
+! Errors: any non-zero status of the library becomes g_logger%fatal, the reference's error behaviour on this path
+! (recursion.f90:1942 'Diagonalization error', :2595 'Chebyshev moments did not converge').
+!------------------------------------------------------------------------------
+module recursion_gpu_mod
+   use, intrinsic :: iso_c_binding
+   use mpi_mod
+   use hamiltonian_mod
+   use energy_mod
+   use recursion_mod
+   use precision_mod, only: rp
+   use math_mod, only: one_over_sqrt_two
+   use string_mod, only: int2str
+   use logger_mod, only: g_logger
+   use timer_mod, only: g_timer
+   use rsrec_binding
+   implicit none
+
+   private
+
+   type, public, extends(recursion) :: recursion_gpu
+   contains
+      procedure :: recur => gpu_recur
+      procedure :: recur_b => gpu_recur_b
+      procedure :: recur_b_ij => gpu_recur_b_ij
+      procedure :: chebyshev_recur => gpu_chebyshev_recur
+      procedure :: zsqr => gpu_zsqr
+   end type recursion_gpu
+
+   interface recursion_gpu
+      procedure :: gpu_constructor
+   end interface recursion_gpu
+
+   public :: rsrec_gpu_shutdown
+
+   !> the per-process device context (lazy)
+   type(c_ptr), save :: g_handle = c_null_ptr
+
+contains
+
+   !> Same construction as recursion.f90:132-143 (pointers + restore_to_default); no device state is created here.
+   function gpu_constructor(hamiltonian_obj, energy_obj) result(obj)
+      type(recursion_gpu) :: obj
+      type(hamiltonian), target, intent(in) :: hamiltonian_obj
+      type(energy), target, intent(in) :: energy_obj
+
+      obj%hamiltonian => hamiltonian_obj
+      obj%lattice => hamiltonian_obj%charge%lattice
+      obj%en => energy_obj
+      obj%control => hamiltonian_obj%charge%lattice%control
+      call obj%restore_to_default()
+   end function gpu_constructor
+
+   subroutine check(rc, where)
+      integer(c_int), intent(in) :: rc
+      character(len=*), intent(in) :: where
+      if (rc /= 0) call g_logger%fatal(where//': '//rsrec_error_string(g_handle), __FILE__, __LINE__)
+   end subroutine check
+
+   !> Create the context on first use and (re)send the tables the recursion reads.
+   !> The caller rebuilds the Hamiltonian before every recur* call (self.f90:777-797), so the blocks are uploaded
+   !> on every call; the lattice tables are constant during a run but small (kk*(nnmax+1) int32).
+   subroutine sync_device(this, upload_lattice)
+      class(recursion_gpu), intent(inout), target :: this
+      logical, intent(in) :: upload_lattice
+      integer(c_int) :: rc, ndev, hoh_i
+      type(c_ptr) :: p_hall, p_hallo
+
+      if (.not. c_associated(g_handle)) then
+         ndev = rsrec_device_count()
+         if (ndev <= 0) call g_logger%fatal('recursion_gpu: no usable GPU (librsrec has no CPU fallback)', __FILE__, __LINE__)
+         rc = rsrec_create(g_handle, int(mod(rank, ndev), c_int))
+         if (rc /= 0) call g_logger%fatal('recursion_gpu: rsrec_create failed', __FILE__, __LINE__)
+      end if
+      if (upload_lattice) then
+         rc = rsrec_set_lattice(g_handle, int(this%lattice%kk, c_int), int(size(this%lattice%nn, 2), c_int), &
+                                c_loc(this%lattice%nn), c_loc(this%lattice%iz), int(this%lattice%nmax, c_int), &
+                                int(this%lattice%ntype, c_int))
+         call check(rc, 'rsrec_set_lattice')
+      end if
+      hoh_i = 0
+      if (this%hamiltonian%hoh) hoh_i = 1
+      p_hall = c_null_ptr
+      p_hallo = c_null_ptr
+      if (this%lattice%nmax > 0) then
+         p_hall = c_loc(this%hamiltonian%hall)
+         p_hallo = c_loc(this%hamiltonian%hallo)
+      end if
+      rc = rsrec_set_hamiltonian(g_handle, int(size(this%hamiltonian%ee, 3), c_int), hoh_i, int(this%control%nsp, c_int), &
+                                 c_loc(this%hamiltonian%ee), c_loc(this%hamiltonian%lsham), c_loc(this%hamiltonian%eeo), &
+                                 c_loc(this%hamiltonian%enim), p_hall, p_hallo)
+      call check(rc, 'rsrec_set_hamiltonian')
+   end subroutine sync_device
+
+   !> Release the device context (optional; call once before MPI_FINALIZE).
+   subroutine rsrec_gpu_shutdown()
+      integer(c_int) :: rc
+      if (c_associated(g_handle)) rc = rsrec_destroy(g_handle)
+      g_handle = c_null_ptr
+   end subroutine rsrec_gpu_shutdown
+
+   !---------------------------------------------------------------------------
+   !> Block recursion for the sites of this rank (replaces recursion.f90:1807-1866)
+   !---------------------------------------------------------------------------
+   subroutine gpu_recur_b(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, j, l, ll, llmax, nloc, i_loc
+      integer(c_int) :: rc
+      integer(c_int), allocatable, target :: seeds(:)
+      complex(rp), allocatable, target :: ab(:, :, :, :), bb(:, :, :, :)
+
+      call get_mpi_variables(rank, this%lattice%nrec)            ! recursion.f90:1816
+      llmax = this%lattice%control%lld
+      nloc = end_atom - start_atom + 1
+      if (nloc <= 0) return
+      allocate (seeds(nloc), ab(18, 18, llmax, nloc), bb(18, 18, llmax, nloc))
+
+      if (this%hamiltonian%local_axis) then
+         ! the reference re-rotates every Hamiltonian block into the spin frame of each site before its chain
+         ! (recursion.f90:1830-1832): H is per site, so sites are sent one at a time
+         do i = start_atom, end_atom
+            i_loc = i - start_atom + 1
+            j = this%lattice%irec(i)
+            call g_logger%info('Block recursion on progress for atom '//int2str(j), __FILE__, __LINE__)
+            call this%hamiltonian%rotate_to_local_axis(this%lattice%symbolic_atoms(i)%potential%mom)
+            call sync_device(this, i == start_atom)
+            seeds(1) = int(j, c_int)
+            rc = rsrec_block_lanczos(g_handle, 1_c_int, c_loc(seeds), int(llmax, c_int), c_loc(ab(1, 1, 1, i_loc)), c_loc(bb(1, 1, 1, i_loc)))
+            call check(rc, 'rsrec_block_lanczos')
+         end do
+      else
+         call sync_device(this, .true.)
+         do i = start_atom, end_atom
+            j = this%lattice%irec(i)
+            call g_logger%info('Block recursion on progress for atom '//int2str(j), __FILE__, __LINE__)
+            seeds(i - start_atom + 1) = int(j, c_int)
+         end do
+         call g_timer%start('H|PSI_n>')       ! the reference's label for the hot loop (recursion.f90:1902); here: all levels of all sites
+         rc = rsrec_block_lanczos(g_handle, int(nloc, c_int), c_loc(seeds), int(llmax, c_int), c_loc(ab), c_loc(bb))
+         call g_timer%stop('H|PSI_n>')
+         call check(rc, 'rsrec_block_lanczos')
+      end if
+
+      do i_loc = 1, nloc                                          ! recursion.f90:1844-1853
+         this%a_b(:, :, 1:llmax, i_loc) = ab(:, :, :, i_loc)
+         this%b2_b(:, :, 1:llmax, i_loc) = bb(:, :, :, i_loc)
+         do ll = 1, llmax
+            do l = 1, 18
+               this%a(ll, l, i_loc, 1) = real(ab(l, l, ll, i_loc))
+               this%b2(ll, l, i_loc, 1) = real(bb(l, l, ll, i_loc))
+            end do
+         end do
+      end do
+      ! debug dump kept for compatibility with existing tooling (recursion.f90:1856-1865)
+      do i = start_atom, end_atom
+         do l = 1, 18
+            write (1000*(1 + rank) + 122, *) 'orbital', l, 'atom', i
+            do ll = 1, llmax
+               write (1000*(1 + rank) + 122, '(2f12.8,4x,2f12.8)') this%a(ll, l, i - start_atom + 1, 1), this%b2(ll, l, i - start_atom + 1, 1)
+            end do
+         end do
+      end do
+   end subroutine gpu_recur_b
+
+   !---------------------------------------------------------------------------
+   !> Four chains per atom pair (replaces recursion.f90:1655-1737)
+   !---------------------------------------------------------------------------
+   subroutine gpu_recur_b_ij(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, j, ij, ij_loc, reci, llmax, nch, c
+      integer(c_int) :: rc
+      integer(c_int), allocatable, target :: seeds(:, :)
+      integer, allocatable :: slot(:)
+      complex(rp), allocatable, target :: coef(:, :), ab(:, :, :, :), bb(:, :, :, :)
+
+      llmax = this%lattice%control%lld
+      allocate (seeds(2, 4*max(end_atom - start_atom + 1, 1)), coef(2, 4*max(end_atom - start_atom + 1, 1)), slot(4*max(end_atom - start_atom + 1, 1)))
+      nch = 0
+      do ij = start_atom, end_atom
+         ij_loc = g2l_map(ij)
+         i = this%lattice%ijpair(ij, 1)
+         j = this%lattice%ijpair(ij, 2)
+         call g_logger%info('Block recursion on progress between atoms '//int2str(i)//' and '//int2str(j), __FILE__, __LINE__)
+         do reci = 1, 4
+            if (i == j .and. reci > 1) cycle                       ! :1705-1706
+            nch = nch + 1
+            seeds(:, nch) = [int(i, c_int), int(j, c_int)]
+            slot(nch) = ij_loc*4 - 4 + reci                        ! :1721
+            if (i == j) then
+               coef(:, nch) = [(1.0_rp, 0.0_rp), (0.0_rp, 0.0_rp)] ! psi(i) = 1 (:1702-1704; the two writes hit the same block)
+            else
+               coef(1, nch) = (1.0_rp, 0.0_rp)*one_over_sqrt_two
+               select case (reci)                                  ! :1679-1700
+               case (1); coef(2, nch) = (1.0_rp, 0.0_rp)*one_over_sqrt_two
+               case (2); coef(2, nch) = (-1.0_rp, 0.0_rp)*one_over_sqrt_two
+               case (3); coef(2, nch) = (0.0_rp, 1.0_rp)*one_over_sqrt_two
+               case (4); coef(2, nch) = (0.0_rp, -1.0_rp)*one_over_sqrt_two
+               end select
+            end if
+         end do
+      end do
+      if (nch == 0) return
+      allocate (ab(18, 18, llmax, nch), bb(18, 18, llmax, nch))
+      call sync_device(this, .true.)
+      rc = rsrec_block_lanczos_seeded(g_handle, int(nch, c_int), 2_c_int, c_loc(seeds), c_loc(coef), int(llmax, c_int), c_loc(ab), c_loc(bb))
+      call check(rc, 'rsrec_block_lanczos_seeded')
+      do c = 1, nch
+         this%a_b(:, :, 1:llmax, slot(c)) = ab(:, :, :, c)
+         this%b2_b(:, :, 1:llmax, slot(c)) = bb(:, :, :, c)
+      end do
+   end subroutine gpu_recur_b_ij
+
+   !---------------------------------------------------------------------------
+   !> b2_b <- sqrt(b2_b) for every level of every local chain (replaces recursion.f90:1980-2023)
+   !---------------------------------------------------------------------------
+   subroutine gpu_zsqr(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: na
+      integer(c_int) :: rc
+      complex(rp), allocatable, target :: buf(:, :, :, :)
+
+      if (this%lattice%njij == 0) then
+         na = atoms_per_process
+      else
+         na = atoms_per_process*4
+      end if
+      if (na <= 0) return
+      call sync_device(this, .false.)
+      allocate (buf(18, 18, this%lattice%control%lld, na))
+      buf = this%b2_b(:, :, 1:this%lattice%control%lld, 1:na)
+      rc = rsrec_zsqr(g_handle, int(this%lattice%control%lld*na, c_int), c_loc(buf))
+      call check(rc, 'rsrec_zsqr')
+      this%b2_b(:, :, 1:this%lattice%control%lld, 1:na) = buf
+   end subroutine gpu_zsqr
+
+   !---------------------------------------------------------------------------
+   !> Chebyshev moments for the sites of this rank (replaces recursion.f90:3057-3130)
+   !---------------------------------------------------------------------------
+   subroutine gpu_chebyshev_recur(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, j, nloc, nmom
+      integer(c_int) :: rc
+      real(rp) :: a, b
+      integer(c_int), allocatable, target :: seeds(:)
+      complex(rp), allocatable, target :: mu(:, :, :, :)
+
+      nloc = end_atom - start_atom + 1
+      if (nloc <= 0) return
+      nmom = 2*this%control%lld + 2
+      a = (this%en%energy_max - this%en%energy_min)/(2 - 0.3)      ! recursion.f90:3078 (0.3 is a default-real literal there too)
+      b = (this%en%energy_max + this%en%energy_min)/2
+      allocate (seeds(nloc), mu(18, 18, nmom, nloc))
+      do i = start_atom, end_atom
+         j = this%lattice%irec(i)
+         call g_logger%info('Chebyshev recursion on progress for atom '//int2str(j), __FILE__, __LINE__)
+         seeds(g2l_map(i)) = int(j, c_int)
+      end do
+      call sync_device(this, .true.)
+      call g_timer%start('<PSI_0|PSI_n>')
+      rc = rsrec_chebyshev(g_handle, int(nloc, c_int), c_loc(seeds), int(this%control%lld, c_int), real(a, c_double), real(b, c_double), c_loc(mu))
+      call g_timer%stop('<PSI_0|PSI_n>')
+      call check(rc, 'rsrec_chebyshev')
+      this%mu_n(:, :, 1:nmom, 1:nloc) = mu
+   end subroutine gpu_chebyshev_recur
+
+   !---------------------------------------------------------------------------
+   !> Scalar Haydock recursion (replaces recursion.f90:3485-3532)
+   !---------------------------------------------------------------------------
+   subroutine gpu_recur(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, nloc, llmax_a
+      integer(c_int) :: rc
+      integer(c_int), allocatable, target :: seeds(:)
+      real(rp), allocatable, target :: a(:, :, :), b2(:, :, :)
+
+      nloc = end_atom - start_atom + 1
+      if (nloc <= 0) return
+      llmax_a = size(this%a, 1)
+      allocate (seeds(nloc), a(llmax_a, 18, nloc), b2(llmax_a, 18, nloc))
+      do i = start_atom, end_atom
+         seeds(g2l_map(i)) = int(this%lattice%irec(i), c_int)
+      end do
+      call sync_device(this, .true.)
+      rc = rsrec_scalar_lanczos(g_handle, int(nloc, c_int), c_loc(seeds), int(this%lattice%control%lld, c_int), int(llmax_a, c_int), c_loc(a), c_loc(b2))
+      call check(rc, 'rsrec_scalar_lanczos')
+      ! the reference fills rows 1..lld of a(:,:,i_loc,1) / b2 and leaves the rest untouched (:3516-3519)
+      this%a(1:this%lattice%control%lld, :, 1:nloc, 1) = a(1:this%lattice%control%lld, :, :)
+      this%b2(1:this%lattice%control%lld, :, 1:nloc, 1) = b2(1:this%lattice%control%lld, :, :)
+   end subroutine gpu_recur
+
+end module recursion_gpu_mod

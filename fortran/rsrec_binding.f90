@@ -1,0 +1,144 @@
+!------------------------------------------------------------------------------
+! rsrec_binding -- iso_c_binding interface of librsrec (include/rsrec.h).
+!
+! The reference is 100 % Fortran and has no FFI today; these are the bind(C)
+! interfaces the GPU recursion type (recursion_gpu.f90) calls.  Every array is
+! passed exactly as the reference stores it (column-major, complex(rp) =
+! interleaved re/im, 1-based atom numbers), so no host-side reshuffling.
+!------------------------------------------------------------------------------
+module rsrec_binding
+   use, intrinsic :: iso_c_binding
+   implicit none
+   public
+
+   interface
+      function rsrec_version() bind(C, name='rsrec_version') result(v)
+         import :: c_int
+         integer(c_int) :: v
+      end function
+
+      function rsrec_device_count() bind(C, name='rsrec_device_count') result(n)
+         import :: c_int
+         integer(c_int) :: n
+      end function
+
+      function rsrec_create(handle, device) bind(C, name='rsrec_create') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), intent(out) :: handle
+         integer(c_int), value :: device
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_destroy(handle) bind(C, name='rsrec_destroy') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_set_lattice(handle, kk, nncols, nn, iz, nmax, ntype) bind(C, name='rsrec_set_lattice') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: kk, nncols, nmax, ntype
+         type(c_ptr), value :: nn, iz
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_set_hamiltonian(handle, nslots, hoh, nsp, ee, lsham, eeo, enim, hall, hallo) &
+         bind(C, name='rsrec_set_hamiltonian') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nslots, hoh, nsp
+         type(c_ptr), value :: ee, lsham, eeo, enim, hall, hallo
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_block_lanczos(handle, nsites, seed_atoms, lld, a_b, b2_b) bind(C, name='rsrec_block_lanczos') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld
+         type(c_ptr), value :: seed_atoms, a_b, b2_b
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_block_lanczos_seeded(handle, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b) &
+         bind(C, name='rsrec_block_lanczos_seeded') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nchains, nseed, lld
+         type(c_ptr), value :: seed_atoms, seed_coef, a_b, b2_b
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_zsqr(handle, nmat, b2_b) bind(C, name='rsrec_zsqr') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nmat
+         type(c_ptr), value :: b2_b
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_chebyshev(handle, nsites, seed_atoms, lld, a, b, mu_n) bind(C, name='rsrec_chebyshev') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld
+         real(c_double), value :: a, b
+         type(c_ptr), value :: seed_atoms, mu_n
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_scalar_lanczos(handle, nsites, seed_atoms, lld, llmax, a, b2) bind(C, name='rsrec_scalar_lanczos') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld, llmax
+         type(c_ptr), value :: seed_atoms, a, b2
+         integer(c_int) :: rc
+      end function
+
+      subroutine rsrec_site_partition(rank, nprocs, nsites, start_atom, end_atom) bind(C, name='rsrec_site_partition')
+         import :: c_int
+         integer(c_int), value :: rank, nprocs, nsites
+         integer(c_int), intent(out) :: start_atom, end_atom
+      end subroutine
+
+      function rsrec_last_error(handle, buf, n) bind(C, name='rsrec_last_error') result(rc)
+         import :: c_int, c_ptr, c_char, c_size_t
+         type(c_ptr), value :: handle
+         character(kind=c_char), intent(out) :: buf(*)
+         integer(c_size_t), value :: n
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_set_option(handle, key, val) bind(C, name='rsrec_set_option') result(rc)
+         import :: c_int, c_ptr, c_char, c_long
+         type(c_ptr), value :: handle
+         character(kind=c_char), intent(in) :: key(*)
+         integer(c_long), value :: val
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_get_timing(handle, out, n) bind(C, name='rsrec_get_timing') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         real(c_double), intent(out) :: out(*)
+         integer(c_int), value :: n
+         integer(c_int) :: rc
+      end function
+   end interface
+
+contains
+
+   !> Error text of a handle as a Fortran string
+   function rsrec_error_string(handle) result(msg)
+      type(c_ptr), intent(in) :: handle
+      character(len=:), allocatable :: msg
+      character(kind=c_char) :: buf(512)
+      integer :: i, rc
+      rc = rsrec_last_error(handle, buf, int(512, c_size_t))
+      msg = ''
+      do i = 1, 512
+         if (buf(i) == c_null_char) exit
+         msg = msg//buf(i)
+      end do
+   end function rsrec_error_string
+
+end module rsrec_binding

@@ -38,6 +38,9 @@ typedef struct rsrec_handle rsrec_t;
 /* Library/ABI version (major*100 + minor). */
 int rsrec_version(void);
 
+/* Number of usable HIP devices (0 if none): the Fortran host maps MPI rank -> device with it (mpi.f90 rank). */
+int rsrec_device_count(void);
+
 /* Create / destroy the per-GPU context.  `device` = HIP device ordinal (the rank's local GPU).
  * Replaces nothing in the reference (its recursion type owns host arrays only, recursion.f90:41-116,
  * allocated in restore_to_default :3713-3790); the drop-in module creates the context lazily on the

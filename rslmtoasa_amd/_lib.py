@@ -15,6 +15,7 @@ _lib = None
 
 _SIGNATURES = {
     "rsrec_version": (C.c_int, []),
+    "rsrec_device_count": (C.c_int, []),
     "rsrec_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "rsrec_destroy": (C.c_int, [C.c_void_p]),
     "rsrec_set_lattice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

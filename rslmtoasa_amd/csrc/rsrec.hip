@@ -70,6 +70,18 @@ struct rsrec_handle {
     int hop_fuses_a = 1;      // 1: the timed H|psi> kernel also forms pmn and the A_n partial (VALU path); 0: pure SpMM (MFMA path)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // regions are purely topological: they are reused while the lattice and the seeds stay the same (every SCF iteration
+    // of the reference calls recur_b with the same lattice%nn and lattice%irec)
+    struct RegionEntry {
+        std::vector<int> seeds;
+        int nlev, napply, flags, epoch, ostride;
+        double atom_steps, block_mults;
+        DevBuf order, cum;
+    };
+    std::vector<RegionEntry*> region_cache;
+    int lattice_epoch = 0;
+    const int* cur_order = nullptr;
+    const int* cur_cum = nullptr;
 };
 
 namespace {
@@ -141,6 +153,12 @@ void grow_region(const rsrec_t* h, const int* seeds, int nseed, int nlev, Region
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int rsrec_version(void) { return 100; }
 
+extern "C" int rsrec_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 extern "C" int rsrec_create(rsrec_t** out, int device) {
     if (!out) return RSREC_ERR_ARG;
     *out = nullptr;
@@ -164,6 +182,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
+    for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->mfma_op.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -246,6 +265,7 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
     HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
     h->have_lattice = true;
+    h->lattice_epoch++;
     h->have_ham = false;   // operator tables depend on nmax/ntype: must be set again
     return RSREC_OK;
 }
@@ -342,6 +362,14 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
                    double& atom_steps, double& block_mults) {
     const int kk = h->kk;
     ostride = grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk;
+    const int flags = (two_pass ? 1 : 0) | (grouped ? 2 : 0) | (nseed << 2);
+    for (auto* e : h->region_cache)
+        if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
+            std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
+            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>();
+            atom_steps += e->atom_steps; block_mults += e->block_mults;
+            return RSREC_OK;
+        }
     std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)nb * nlev);
     std::vector<double> as(nb, 0.0), bm(nb, 0.0);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -401,12 +429,25 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         }
         as[c] = a_s; bm[c] = b_m;
     }
-    for (int c = 0; c < nb; ++c) { atom_steps += as[c]; block_mults += bm[c]; }
-    HIPCK(h, h->d_order.reserve(order.size() * 4));
-    HIPCK(h, h->d_cum.reserve(cum.size() * 4));
-    HIPCK(h, hipMemcpyAsync(h->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipMemcpyAsync(h->d_cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
+    double as_sum = 0.0, bm_sum = 0.0;
+    for (int c = 0; c < nb; ++c) { as_sum += as[c]; bm_sum += bm[c]; }
+    atom_steps += as_sum; block_mults += bm_sum;
+    if (h->region_cache.size() >= 256) {          // bounded: drop everything (the engine is idle between calls)
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
+        h->region_cache.clear();
+    }
+    auto* e = new rsrec_handle::RegionEntry();
+    e->seeds.assign(seeds0, seeds0 + (size_t)nb * nseed);
+    e->nlev = nlev; e->napply = napply; e->flags = flags; e->epoch = h->lattice_epoch; e->ostride = ostride;
+    e->atom_steps = as_sum; e->block_mults = bm_sum;
+    h->region_cache.push_back(e);
+    HIPCK(h, e->order.reserve(order.size() * 4));
+    HIPCK(h, e->cum.reserve(cum.size() * 4));
+    HIPCK(h, hipMemcpyAsync(e->order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(e->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
+    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>();
     return RSREC_OK;
 }
 
@@ -493,7 +534,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
 
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
@@ -664,7 +705,7 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
         double* p0 = h->d_vec[0].as<double>();
@@ -769,7 +810,7 @@ extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         ChainView CV;
-        CV.order = h->d_order.as<int>(); CV.cum = h->d_cum.as<int>(); CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
         for (int v = 0; v < 2; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nc * velems * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(ca, 0, (size_t)nch * 2 * lld * sizeof(double), h->stream));
         k_scalar_seed<<<nc, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), cb, lld);

@@ -1,0 +1,74 @@
+"""End-to-end drop-in test: the reference's own SCF workflow (compiled reference modules) with the GPU recursion type
+(fortran/recursion_gpu.f90) swapped in, against the reference's committed expected values
+(tests/scf/references/*/ref.json and tests/regression/bccFe_lanczos/Fe.nml.ref, copied as data to tests/golden/scf/).
+
+The binary oracle/_ref/rslmto_gpu.x is linked in the build container by fortran/build.sh from the reference's object
+code + our Fortran shim + librsrec.so; it travels to the GPU box with oracle/_ref/.  Comparison rule = the reference's
+own (tests/run_test.py:201-219): a value fails only if BOTH abs and rel differences exceed the tolerance."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from oracle.make_fixtures import patch_namelist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCF = os.path.join(ROOT, "tests", "golden", "scf")
+EXE = os.path.join(ROOT, "oracle", "_ref", "rslmto_gpu.x")
+MANIFEST = json.load(open(os.path.join(SCF, "manifest.json")))
+
+pytestmark = pytest.mark.gpu
+
+
+def read_nml_value(path, key, index=None):
+    txt = open(path).read()
+    m = re.search(r"(?im)^\s*%s(\(:\))?\s*=\s*(.+)$" % re.escape(key), txt)
+    assert m, "%s not found in %s" % (key, path)
+    vals = [float(v.replace("D", "E").replace("d", "e")) for v in re.findall(r"[-+]?[0-9]*\.?[0-9]+(?:[eEdD][-+]?[0-9]+)?", m.group(2))]
+    return vals[0] if index is None else vals[index - 1]
+
+
+def close(got, exp, abs_tol, rel_tol):
+    d = abs(got - exp)
+    return d <= abs_tol or d <= rel_tol * abs(exp)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_scf_workflow_with_gpu_recursion(name, tmp_path):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/rslmto_gpu.x not built (needs the reference sources: build container only)")
+    case = MANIFEST[name]
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(SCF, case["inputs"]), work)
+    inp = work / "input.nml"
+    inp.write_text(patch_namelist(inp.read_text(), case["patch"]))
+    env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
+    r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec %s" % EXE], cwd=work, env=env, capture_output=True, text=True, timeout=1500)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    assert "fatal" not in log.lower(), log[-3000:]                      # tests/run_test.py:119-131
+    at, rt = case["abs_tol"], case["rel_tol"]
+    bad = []
+    for fn, keys in case["expected"].get("nml", {}).items():
+        for key, exp in keys.items():
+            if isinstance(exp, dict):
+                for idx, e in exp.items():
+                    got = read_nml_value(work / fn, key, int(idx))
+                    if not close(got, e, at, rt):
+                        bad.append((fn, key, idx, got, e))
+            else:
+                got = read_nml_value(work / fn, key)
+                if not close(got, exp, at, rt):
+                    bad.append((fn, key, got, exp))
+    for fn, rows in case["expected"].get("text", {}).items():
+        lines = (work / fn).read_text().splitlines()
+        for row, cols in rows.items():
+            vals = lines[int(row) - 1].split()
+            for col, e in cols.items():
+                got = float(vals[int(col) - 1])
+                if not close(got, e, at, rt):
+                    bad.append((fn, row, col, got, e))
+    assert not bad, bad
