@@ -34,6 +34,7 @@ from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recur
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); rate measured here: profiles/ubench_f64_r01.txt
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
+HOP_TRAFFIC_BYTES_PER_LAUNCH = None   # HBM bytes per H|psi> launch from rocprofv3 PMC passes (profiles/); None until measured
 BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
 
 
@@ -125,20 +126,16 @@ def main():
     if args.batch:
         rec.set_option("batch", args.batch)
 
-    gather = None
-    if world > 1:
-        gather = torch.zeros((2, args.lld, 18, nsites_total), dtype=torch.float64, device="cuda")
+    from rslmtoasa_amd.parallel import allgather_sites
 
     def step():
         rec.recur_b()
         if world > 1:
-            # the path's one exchange: zero-padded all-reduce == all-gather of per-site results (bands.f90:271-274)
+            # the path's one exchange: zero-padded all-reduce == all-gather of the per-site results (bands.f90:271-274),
+            # here the diagonal coefficients a(ll,l,site), b2(ll,l,site) that feed the LDOS continued fraction
             start, end = rec._my_sites()[:2]
             nloc = end - start + 1
-            gather.zero_()
-            gather[0, :, :, start - 1:end] = torch.from_numpy(np.ascontiguousarray(rec.a[:args.lld, :, :nloc, 0])).cuda()
-            gather[1, :, :, start - 1:end] = torch.from_numpy(np.ascontiguousarray(rec.b2[:args.lld, :, :nloc, 0])).cuda()
-            dist.all_reduce(gather, op=dist.ReduceOp.SUM)
+            allgather_sites([rec.a[:args.lld, :, :nloc, 0], rec.b2[:args.lld, :, :nloc, 0]], rank, world, nsites_total, dist=dist, device="cuda")
 
     for _ in range(args.warmup):
         step()
@@ -168,8 +165,9 @@ def main():
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + 5.0 * tm_acc["atom_steps"])
         flop_total = flop_rank * world
         bytes_total = BYTES_PER_ATOM_STEP * tm_acc["atom_steps"] * world
-        # dominant kernel = H|psi> (SpMM + fused pmn update + A_n partial): 46656*(block multiplies + 1 per atom-step for A_n)
-        hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + tm_acc["atom_steps"])
+        # dominant kernel = H|psi>: the block SpMM, 46656 flop per block multiply (+ 46656 per atom-step when the kernel
+        # also forms the A_n partial: VALU kernels and the fused MFMA variant)
+        hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + (tm_acc["atom_steps"] if tm.get("hop_fuses_a", 1.0) else 0.0))
         hop_s = tm_acc["hop_ms"] * 1e-3
         achieved = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
         out = {
@@ -193,7 +191,7 @@ def main():
             "device_ms_per_step": tm_acc["total_ms"] / args.steps,
             "host_ms_per_step": tm_acc["host_ms"] / args.steps,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "H|psi> (hop)", "launches": tm_acc["hop_launches"],
+                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH, "kernel": "k_mfma_spmm (H|psi> block SpMM)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
                          "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
                                       "note": "whole recursion level, algorithmic 51840 B per atom-step"}},

@@ -126,9 +126,9 @@ class Recursion:
         self._check(self._L.rsrec_set_option(self._h, key.encode(), int(value)))
 
     def timing(self):
-        out = (C.c_double * 7)()
-        self._L.rsrec_get_timing(self._h, out, 7)
-        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms")
+        out = (C.c_double * 8)()
+        self._L.rsrec_get_timing(self._h, out, 8)
+        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a")
         return dict(zip(keys, list(out)))
 
     # -- state (restore_to_default, recursion.f90:3713-3825) --------------------------------------------
