@@ -556,6 +556,17 @@ __global__ __launch_bounds__(1024) void k_reduce_a_mf(const double* __restrict__
     emit_rhs_frags(Am, -1.0, afrags + (size_t)chain * 27 * 64);
 }
 
+// complex (VALU-layout) partials -> A_n and its fragment table (used when a VALU epilogue produced the partials)
+__global__ __launch_bounds__(1024) void k_reduce_a_c2f(const double2* __restrict__ partial, int nblk, double2* a_out, size_t astride, double* afrags) {
+    __shared__ double2 lds[3 * BLK];
+    __shared__ double2 Am[BLK];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_partials(partial + (size_t)chain * nblk * BLK, nblk, 1, 0, lds);
+    if (threadIdx.x < BLK) { a_out[chain * astride + threadIdx.x] = c; Am[threadIdx.x] = c; }
+    __syncthreads();
+    emit_rhs_frags(Am, -1.0, afrags + (size_t)chain * 27 * 64);
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_b_eig_mf(const double* __restrict__ partial, int nblk, double2* b2_out, size_t bstride, double2* Bmats,
                                                          double* bfrags, int* status) {
     __shared__ double lds[1296];

@@ -128,7 +128,9 @@ struct ApplyArgs {
     double a, b;
 };
 
-template <int MODE, class L>
+// PRE = true: the neighbour sum was already formed by the matrix-core SpMM (kernels_mfma.hpp) and sits in G.in; this kernel
+// then only runs the per-atom epilogue of the mode (combine / scale-shift / moments).
+template <int MODE, class L, bool PRE = false>
 __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, ApplyArgs G) {
     __shared__ double2 red[BLK];
     const int chain = blockIdx.y;
@@ -152,7 +154,12 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
         double2 acc[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) acc[r] = make_double2(0, 0);
-        apply_column<L>(P, second_pass, i, in, c, acc);
+        if (PRE) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) acc[r] = L::ld(in + (size_t)BLD * i, r, c);
+        } else {
+            apply_column<L>(P, second_pass, i, in, c, acc);
+        }
         if (MODE == AM_STORE) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) L::st(G.out + bo, r, c, acc[r]);

@@ -482,7 +482,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int nsteps = lld - 1;
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
-    const int nvec = (hoh || MFMA) ? 3 : 2;
+    const int nvec = MFMA ? (hoh ? 4 : 3) : (hoh ? 3 : 2);
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -500,6 +500,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     double* psi = h->d_vec[0].as<double>();
     double* pmn = h->d_vec[1].as<double>();
     double* hpsi = h->d_vec[2].as<double>();
+    double* t2 = h->d_vec[3].as<double>();
     double2* dA = h->d_coefA.as<double2>();
     double2* dB = h->d_coefB.as<double2>();
     double2* partial = h->d_partial.as<double2>();
@@ -513,7 +514,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const size_t orth_lds = TILE_ATOMS * BLK * sizeof(double2);
     hipEvent_t ev_begin = next_event(h);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
-    h->hop_fuses_a = (MFMA && !(h->opt_post != 1 && h->opt_fuse)) ? 0 : 1;
+    h->hop_fuses_a = (MFMA && (hoh || !(h->opt_post != 1 && h->opt_fuse))) ? 0 : 1;
 
     for (int c0 = 0; c0 < nchains; c0 += B) {
         const int nb = std::min(B, nchains - c0);
@@ -588,6 +589,25 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                     e1 = next_event(h);
                 }
+            } else if (MFMA) {
+                // hoh on the matrix cores: t1 = h psi, t2 = (h o) t1, then the per-atom combine/epilogue (VALU) and MFMA orth/update
+                const double* f0 = h->mfma_op.set_ptr(0);
+                const double* f1 = h->mfma_op.set_ptr(1);
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems};
+                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, f0, psi, hpsi, nullptr);
+                SD.level = lv_final;
+                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, f1, hpsi, t2, nullptr);
+                e1 = next_event(h);
+                G.in = t2; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                k_apply<AM_HOH_LANCZOS, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                k_reduce_a_c2f<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride, afrags);
+                k_mfma_orth<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
+                k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                               h->d_status.as<int>());
+                k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                hop_ev.emplace_back(e0, e1);
+                h->n_hop_launch += 2;
+                continue;
             } else {
                 G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
                 k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
@@ -631,7 +651,7 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
     reset_timing(h);
     if (nchains == 0) return RSREC_OK;
     // kernels: 0 = auto (MFMA where implemented), 1 = VALU reference kernels, 2 = MFMA
-    const bool use_mfma = (h->opt_kernels != 1) && !h->hoh;
+    const bool use_mfma = (h->opt_kernels != 1);
     if (use_mfma) return run_block_lanczos<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
     return run_block_lanczos<LayoutCM, false>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
 }
@@ -659,22 +679,18 @@ extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
     return RSREC_OK;
 }
 
-extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
-    int rc = check_ready(h, "rsrec_chebyshev");
-    if (rc) return rc;
-    if (nsites < 0 || lld < 1 || !mu_n || (nsites > 0 && !seed_atoms) || a == 0.0) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: bad argument");
-    for (int q = 0; q < nsites; ++q)
-        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
-    HIPCK(h, hipSetDevice(h->device));
-    reset_timing(h);
-    if (nsites == 0) return RSREC_OK;
+namespace {
+
+template <class L, bool MFMA>
+int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+    int rc = 0;
     const int kk = h->kk;
     const bool hoh = h->hoh != 0;
     const int napply = lld + 1;                                  // first moment + lld steps
     const int nlev = (hoh ? 2 * napply : napply) + 1;
     const int nmom = 2 * lld + 2;
     const size_t velems = (size_t)(kk + 1) * BLD;
-    const int nvec = hoh ? 4 : 3;
+    const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -698,7 +714,7 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
         std::vector<double> coef((size_t)nb * 2);
         for (int q = 0; q < nb; ++q) { seeds0[q] = seed_atoms[c0 + q] - 1; coef[2 * q] = 1.0; coef[2 * q + 1] = 0.0; }
         int ostride = kk;
-        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, false, ostride, h->n_atom_steps, h->n_block_mult);
+        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -712,7 +728,9 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
         double* p1 = h->d_vec[1].as<double>();
         double* p2 = h->d_vec[2].as<double>();
         double* tmp = h->d_vec[3].as<double>();
-        k_seed<LayoutCM><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
+        double* tmp2 = h->d_vec[4].as<double>();
+        const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+        k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
         k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride);                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
@@ -724,16 +742,31 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
             G.a = a; G.b = b;
             double* src = first ? p0 : p1;
             double* dst = first ? p1 : p2;
-            if (!hoh) {
+            if (MFMA) {
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems};
+                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(0), src, tmp, nullptr);
+                if (hoh) {
+                    SD.level = lv_final;
+                    k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(1), tmp, tmp2, nullptr);
+                }
+                G.in = hoh ? tmp2 : tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
+                if (!hoh) {
+                    if (first) k_apply<AM_CHEB1, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    else k_apply<AM_CHEBN, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                } else {
+                    if (first) k_apply<AM_HOH_CHEB1, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    else k_apply<AM_HOH_CHEBN, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                }
+            } else if (!hoh) {
                 G.in = src; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
-                if (first) k_apply<AM_CHEB1, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                else k_apply<AM_CHEBN, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                if (first) k_apply<AM_CHEB1, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_CHEBN, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             } else {
                 G.in = src; G.out = tmp; G.level = 2 * t - 1;
-                k_apply<AM_STORE, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 G.in = tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
-                if (first) k_apply<AM_HOH_CHEB1, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                else k_apply<AM_HOH_CHEBN, LayoutCM><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                if (first) k_apply<AM_HOH_CHEB1, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                else k_apply<AM_HOH_CHEBN, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
             }
             hipEvent_t e1 = next_event(h);
             hop_ev.emplace_back(e0, e1);
@@ -754,6 +787,21 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
     HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
     if (status & 2) return fail(h, RSREC_ERR_DIVERGED, "Chebyshev moments did not converge. Check energy limits energy_min and energy_max");
     return RSREC_OK;
+}
+
+}  // namespace
+
+extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+    int rc = check_ready(h, "rsrec_chebyshev");
+    if (rc) return rc;
+    if (nsites < 0 || lld < 1 || !mu_n || (nsites > 0 && !seed_atoms) || a == 0.0) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: bad argument");
+    for (int q = 0; q < nsites; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nsites == 0) return RSREC_OK;
+    if (h->opt_kernels != 1) return run_chebyshev<LayoutRM, true>(h, nsites, seed_atoms, lld, a, b, mu_n);
+    return run_chebyshev<LayoutCM, false>(h, nsites, seed_atoms, lld, a, b, mu_n);
 }
 
 extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, int llmax, double* a, double* b2) {
