@@ -3,7 +3,7 @@
 !
 ! `type(recursion_gpu)` EXTENDS the reference's `type(recursion)` (source/recursion.f90:41-116) and overrides
 ! exactly the hot-path type-bound procedures
-!     recur_b (:1807)   recur_b_ij (:1655)   chebyshev_recur (:3057)   recur (:3485)   zsqr (:1980)
+!     recur_b (:1807)   recur_b_ij (:1655)   chebyshev_recur (:3057)   chebyshev_recur_ij (:2376)   recur (:3485)   zsqr (:1980)
 ! with calls into librsrec (hand-written HIP kernels behind the C ABI of include/rsrec.h).  Everything else --
 ! data members a, b2, a_b, b2_b, mu_n (same shapes, same index order), the terminator routines get_terminf / bpopt /
 ! emami used by green.f90 and density_of_states.f90, restore_to_default -- is inherited unchanged, and every consumer
@@ -41,6 +41,7 @@ module recursion_gpu_mod
       procedure :: recur_b => gpu_recur_b
       procedure :: recur_b_ij => gpu_recur_b_ij
       procedure :: chebyshev_recur => gpu_chebyshev_recur
+      procedure :: chebyshev_recur_ij => gpu_chebyshev_recur_ij
       procedure :: zsqr => gpu_zsqr
    end type recursion_gpu
 
@@ -204,7 +205,7 @@ contains
             seeds(:, nch) = [int(i, c_int), int(j, c_int)]
             slot(nch) = ij_loc*4 - 4 + reci                        ! :1721
             if (i == j) then
-               coef(:, nch) = [(1.0_rp, 0.0_rp), (0.0_rp, 0.0_rp)] ! psi(i) = 1 (:1702-1704; the two writes hit the same block)
+               coef(:, nch) = [(1.0_rp, 0.0_rp), (1.0_rp, 0.0_rp)] ! asign = bsign = 1 (:1702-1704); seeds are assigned in order
             else
                coef(1, nch) = (1.0_rp, 0.0_rp)*one_over_sqrt_two
                select case (reci)                                  ! :1679-1700
@@ -279,6 +280,54 @@ contains
       call check(rc, 'rsrec_chebyshev')
       this%mu_n(:, :, 1:nmom, 1:nloc) = mu
    end subroutine gpu_chebyshev_recur
+
+   !---------------------------------------------------------------------------
+   !> Chebyshev moments of the four chains per atom pair (replaces recursion.f90:2376-2487)
+   !---------------------------------------------------------------------------
+   subroutine gpu_chebyshev_recur_ij(this)
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, j, ij, ij_loc, reci, nch, c, nmom
+      integer(c_int) :: rc
+      real(rp) :: a, b
+      integer(c_int), allocatable, target :: seeds(:, :)
+      integer, allocatable :: slot(:)
+      complex(rp), allocatable, target :: coef(:, :), mu(:, :, :, :)
+
+      nch = 4*max(end_atom - start_atom + 1, 0)
+      if (nch <= 0) return
+      nmom = 2*this%control%lld + 2
+      a = (this%en%energy_max - this%en%energy_min)/(2 - 0.3)
+      b = (this%en%energy_max + this%en%energy_min)/2
+      allocate (seeds(2, nch), coef(2, nch), slot(nch), mu(18, 18, nmom, nch))
+      c = 0
+      do ij = start_atom, end_atom
+         ij_loc = g2l_map(ij)
+         i = this%lattice%ijpair(ij, 1)
+         j = this%lattice%ijpair(ij, 2)
+         call g_logger%info(int2str(rank)//': Chebyshev recursion on progress between atoms '//int2str(i)//' and '//int2str(j), __FILE__, __LINE__)
+         do reci = 1, 4                                            ! no i == j special case in the reference (:2403-2448)
+            c = c + 1
+            seeds(:, c) = [int(i, c_int), int(j, c_int)]
+            slot(c) = ij_loc*4 - 4 + reci
+            coef(1, c) = (1.0_rp, 0.0_rp)*one_over_sqrt_two
+            select case (reci)
+            case (1); coef(2, c) = (1.0_rp, 0.0_rp)*one_over_sqrt_two
+            case (2); coef(2, c) = (-1.0_rp, 0.0_rp)*one_over_sqrt_two
+            case (3); coef(2, c) = (0.0_rp, 1.0_rp)*one_over_sqrt_two
+            case (4); coef(2, c) = (0.0_rp, -1.0_rp)*one_over_sqrt_two
+            end select
+         end do
+      end do
+      call sync_device(this, .true.)
+      call g_timer%start('<PSI_0|PSI_n>')
+      rc = rsrec_chebyshev_seeded(g_handle, int(nch, c_int), 2_c_int, c_loc(seeds), c_loc(coef), int(this%control%lld, c_int), &
+                                  real(a, c_double), real(b, c_double), c_loc(mu))
+      call g_timer%stop('<PSI_0|PSI_n>')
+      call check(rc, 'rsrec_chebyshev_seeded')
+      do c = 1, nch
+         this%mu_n(:, :, 1:nmom, slot(c)) = mu(:, :, :, c)
+      end do
+   end subroutine gpu_chebyshev_recur_ij
 
    !---------------------------------------------------------------------------
    !> Scalar Haydock recursion (replaces recursion.f90:3485-3532)

@@ -86,6 +86,16 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_chebyshev_seeded(handle, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n) &
+         bind(C, name='rsrec_chebyshev_seeded') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nchains, nseed, lld
+         real(c_double), value :: a, b
+         type(c_ptr), value :: seed_atoms, seed_coef, mu_n
+         integer(c_int) :: rc
+      end function
+
       function rsrec_scalar_lanczos(handle, nsites, seed_atoms, lld, llmax, a, b2) bind(C, name='rsrec_scalar_lanczos') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

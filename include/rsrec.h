@@ -72,8 +72,9 @@ int rsrec_set_hamiltonian(rsrec_t *h, int nslots, int hoh, int nsp, const double
  * b2_b holds B^2 (NOT its square root: the reference takes the root later in zsqr). */
 int rsrec_block_lanczos(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, double *a_b, double *b2_b);
 
-/* Same with general seeds: chain c starts from sum_k coef(k,c) * I18 placed on atom seed(k,c), k = 1..nseed.
+/* Same with general seeds: chain c starts from coef(k,c) * I18 placed on atom seed(k,c), k = 1..nseed.
  * Replaces the four-chain seeds of recur_b_ij (recursion.f90:1655-1800: (psi_i +- psi_j)/sqrt2, (psi_i +- i psi_j)/sqrt2).
+ * Seeds are ASSIGNED in order, psi(l,l,seed(k,c)) = coef(k,c): a later seed on the same atom overwrites (as :1709-1714 do).
  *   seed_atoms : int32 (nseed, nchains);  seed_coef : complex (nseed, nchains) */
 int rsrec_block_lanczos_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
                                int lld, double *a_b, double *b2_b);
@@ -88,6 +89,12 @@ int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);
  *   mu_n : complex (18,18,2*lld+2,nsites) out
  * Returns RSREC_ERR_DIVERGED if sum(real(mu_n(:,:,2ll+2))) > 1000 at any step (:2594). */
 int rsrec_chebyshev(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, double a, double b, double *mu_n);
+
+/* Same with general seeds, psi0(l,l,seed(k,c)) = coef(k,c) in order.  Replaces chebyshev_recur_ij (recursion.f90:2376-2487),
+ * whose four chains per pair start from (psi_i +- psi_j)/sqrt2 and (psi_i +- i psi_j)/sqrt2; both new moments are tested
+ * against the 1000 bound (:2484).  seed_atoms int32 (nseed, nchains), seed_coef complex (nseed, nchains), nseed <= 8. */
+int rsrec_chebyshev_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
+                           int lld, double a, double b, double *mu_n);
 
 /* Scalar Haydock recursion, one chain per (site, orbital).  Replaces recur (recursion.f90:3485-3532),
  * crecal (:3423-3478), hop (:3310-3416).

@@ -15,7 +15,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x52534658
-KIND_BLOCK, KIND_CHEB, KIND_SCALAR = 0, 1, 2
+KIND_BLOCK, KIND_CHEB, KIND_SCALAR, KIND_BLOCK_IJ, KIND_CHEB_IJ = 0, 1, 2, 3, 4
 
 
 def _rd(f, dtype, shape):
@@ -54,6 +54,9 @@ def read_fixture_bin(path):
 
 
 def _read_outputs(f, d, kind, lld, nrec, llmax):
+    if kind in (KIND_BLOCK_IJ, KIND_CHEB_IJ):
+        nrec = 4 * (nrec // 2)        # nrec counts the 2*npairs atoms of the pair list; outputs have 4 chains per pair
+        kind -= 3
     if kind == KIND_BLOCK:
         d["a_b"] = _rd(f, np.complex128, (18, 18, lld, nrec))
         d["b2_b"] = _rd(f, np.complex128, (18, 18, lld, nrec))

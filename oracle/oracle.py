@@ -76,6 +76,27 @@ class Oracle:
         assert rc == 0
         return a_b, b2_b
 
+    def block_lanczos_seeded(self, seeds, coefs, lld):
+        """seeds (nchains, nseed) int, coefs (nchains, nseed) complex"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        coefs = np.ascontiguousarray(coefs, dtype=np.complex128)
+        n, ns = seeds.shape
+        a_b = np.zeros((18, 18, lld, n), np.complex128, order="F")
+        b2_b = np.zeros_like(a_b)
+        rc = lib().orc_block_lanczos_seeded(C.byref(self.P), n, ns, seeds.ctypes.data_as(C.c_void_p), coefs.ctypes.data_as(C.c_void_p), lld,
+                                            a_b.ctypes.data_as(C.c_void_p), b2_b.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return a_b, b2_b
+
+    def chebyshev_seeded(self, seeds, coefs, lld, a, b):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        coefs = np.ascontiguousarray(coefs, dtype=np.complex128)
+        n, ns = seeds.shape
+        mu = np.zeros((18, 18, 2 * lld + 2, n), np.complex128, order="F")
+        rc = lib().orc_chebyshev_seeded(C.byref(self.P), n, ns, seeds.ctypes.data_as(C.c_void_p), coefs.ctypes.data_as(C.c_void_p), lld,
+                                        C.c_double(a), C.c_double(b), mu.ctypes.data_as(C.c_void_p))
+        return mu, rc
+
     def chebyshev(self, seeds, lld, a, b):
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         n = len(seeds)

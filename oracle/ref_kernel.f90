@@ -25,7 +25,7 @@ program ref_kernel
    type(charge), target :: charge_obj
    type(hamiltonian), target :: hamiltonian_obj
    type(recursion), target :: recursion_obj
-   integer :: u, magic, version, kk, nncols, nmax, ntype, nrec, lld, nsp, hoh_i, kind_rec, nslots, llmax
+   integer :: u, magic, version, kk, nncols, nmax, ntype, nrec, lld, nsp, hoh_i, kind_rec, nslots, llmax, npairs, nchains
    real(rp) :: emin, emax
    integer :: t0, t1, rate
 
@@ -48,6 +48,8 @@ program ref_kernel
    case (0); control_obj%recur = 'block'
    case (1); control_obj%recur = 'chebyshev'
    case (2); control_obj%recur = 'lanczos'
+   case (3); control_obj%recur = 'block'        ! recur_b_ij: four chains per atom pair (recursion.f90:1655)
+   case (4); control_obj%recur = 'chebyshev'    ! chebyshev_recur_ij (recursion.f90:2376)
    end select
 
    lattice_obj%control => control_obj
@@ -61,6 +63,15 @@ program ref_kernel
    read (u) lattice_obj%iz
    read (u) lattice_obj%nn
    read (u) lattice_obj%irec
+   npairs = 0
+   if (kind_rec >= 3) then
+      ! for the pair variants `irec` carries the pairs: (i_1, j_1, i_2, j_2, ...)
+      npairs = nrec/2
+      lattice_obj%njij = npairs
+      allocate (lattice_obj%ijpair(npairs, 2))
+      lattice_obj%ijpair(:, 1) = lattice_obj%irec(1:nrec:2)
+      lattice_obj%ijpair(:, 2) = lattice_obj%irec(2:nrec:2)
+   end if
 
    charge_obj%lattice => lattice_obj
    hamiltonian_obj%charge => charge_obj
@@ -84,7 +95,11 @@ program ref_kernel
    energy_obj%energy_min = emin
    energy_obj%energy_max = emax
 
-   call get_mpi_variables(rank, nrec)
+   if (kind_rec >= 3) then
+      call get_mpi_variables(rank, npairs)
+   else
+      call get_mpi_variables(rank, nrec)
+   end if
    recursion_obj = recursion(hamiltonian_obj, energy_obj)
 
    call system_clock(t0, rate)
@@ -96,6 +111,10 @@ program ref_kernel
       call recursion_obj%chebyshev_recur()
    case (2)
       call recursion_obj%recur()
+   case (3)
+      call recursion_obj%recur_b_ij()
+   case (4)
+      call recursion_obj%chebyshev_recur_ij()
    end select
    call g_timer%stop('recursion')
    call system_clock(t1)
@@ -105,10 +124,10 @@ program ref_kernel
    open (newunit=u, file='kernel_out.bin', access='stream', form='unformatted', status='replace')
    write (u) int(z'52534658'), 1, kind_rec
    select case (kind_rec)
-   case (0)
+   case (0, 3)
       write (u) recursion_obj%a_b
       write (u) recursion_obj%b2_b
-   case (1)
+   case (1, 4)
       write (u) recursion_obj%mu_n
    case (2)
       write (u) recursion_obj%a(:, :, :, 1)

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_zsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rsrec_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "rsrec_chebyshev_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "rsrec_scalar_lanczos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_site_partition": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rsrec_last_error": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

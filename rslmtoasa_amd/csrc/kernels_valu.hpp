@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_zsqr(double2* mats, int* status) {
 
 // Chebyshev moment reductions.  first: mu[1] = sum(psi0^H psi1).  else: mu[2ll] = 2 d1 - mu[0], mu[2ll+1] = 2 d2 - mu[1]
 // (0-based moment index; recursion.f90:2591-2592) and the divergence test of :2594.
-__global__ __launch_bounds__(1024) void k_reduce_cheb(const double2* __restrict__ partial, int nblk, int first, int ll, double2* mu, size_t mustride, int* status) {
+__global__ __launch_bounds__(1024) void k_reduce_cheb(const double2* __restrict__ partial, int nblk, int first, int ll, double2* mu, size_t mustride, int* status, int check_both) {
     __shared__ double2 lds[3 * BLK];
     __shared__ double tr[BLK];
     const int chain = blockIdx.x, tid = threadIdx.x;
@@ -445,32 +445,30 @@ __global__ __launch_bounds__(1024) void k_reduce_cheb(const double2* __restrict_
         m[(size_t)(2 * ll) * BLK + tid] = o1;
         m[(size_t)(2 * ll + 1) * BLK + tid] = o2;
         tr[tid] = o2.x;
+        if (check_both) lds[tid] = make_double2(o1.x, 0.0);
     }
     __syncthreads();
     if (tid == 0) {
-        double s = 0.0;
-        for (int e = 0; e < BLK; ++e) s += tr[e];
-        if (s > 1000.0) atomicOr(status, 2);
+        double s = 0.0, s1 = 0.0;
+        for (int e = 0; e < BLK; ++e) { s += tr[e]; if (check_both) s1 += lds[e].x; }
+        if (s > 1000.0 || (check_both && s1 > 1000.0)) atomicOr(status, 2);   // :2594 (and :2484 for the pair variant)
     }
 }
 
-// psi(:,:,seed) = coef * I18 for every seed of every chain
+// psi(l,l,seed_k) = coef_k for k = 1..nseed IN ORDER (a later seed on the same atom overwrites, recursion.f90:1709-1714)
 template <class L>
 __global__ void k_seed(double* psi, size_t vstride, const int* seed_atoms, const double2* seed_coef, int nseed) {
     const int chain = blockIdx.x;
-    for (int s = 0; s < nseed; ++s) {
-        const int atom = seed_atoms[chain * nseed + s];
-        const double2 cf = seed_coef[chain * nseed + s];
-        if (threadIdx.x < NB) {
-            double* b = psi + chain * vstride + (size_t)BLD * atom;
-            const double2 v = L::ld(b, threadIdx.x, threadIdx.x);
-            L::st(b, threadIdx.x, threadIdx.x, make_double2(v.x + cf.x, v.y + cf.y));
+    if (threadIdx.x < NB)
+        for (int s = 0; s < nseed; ++s) {
+            const int atom = seed_atoms[chain * nseed + s];
+            L::st(psi + chain * vstride + (size_t)BLD * atom, threadIdx.x, threadIdx.x, seed_coef[chain * nseed + s]);
         }
-    }
 }
-__global__ void k_set_identity(double2* m, size_t stride) {
+__global__ void k_set_identity(double2* m, size_t stride, const double* scale = nullptr) {
     double2* p = m + blockIdx.x * stride;
-    for (int e = threadIdx.x; e < BLK; e += blockDim.x) p[e] = make_double2((e % NB) == (e / NB) ? 1.0 : 0.0, 0.0);
+    const double sc = scale ? scale[blockIdx.x] : 1.0;
+    for (int e = threadIdx.x; e < BLK; e += blockDim.x) p[e] = make_double2((e % NB) == (e / NB) ? sc : 0.0, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -682,7 +682,7 @@ extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
 namespace {
 
 template <class L, bool MFMA>
-int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld, double a, double b, double* mu_n) {
     int rc = 0;
     const int kk = h->kk;
     const bool hoh = h->hoh != 0;
@@ -699,8 +699,8 @@ int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, do
     HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
-    HIPCK(h, h->d_seed.reserve((size_t)B * 4));
-    HIPCK(h, h->d_seedcoef.reserve((size_t)B * sizeof(double2)));
+    HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
+    HIPCK(h, h->d_seedcoef.reserve((size_t)B * (nseed + 1) * sizeof(double2)));
     HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
     const DevProblem P = make_problem(h);
     const size_t mstride = (size_t)nmom * BLK;
@@ -710,11 +710,27 @@ int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, do
     for (int c0 = 0; c0 < nsites; c0 += B) {
         const int nb = std::min(B, nsites - c0);
         const auto th0 = std::chrono::steady_clock::now();
-        std::vector<int> seeds0(nb);
-        std::vector<double> coef((size_t)nb * 2);
-        for (int q = 0; q < nb; ++q) { seeds0[q] = seed_atoms[c0 + q] - 1; coef[2 * q] = 1.0; coef[2 * q + 1] = 0.0; }
+        std::vector<int> seeds0((size_t)nb * nseed);
+        std::vector<double> coef((size_t)nb * nseed * 2 + nb);     // coefficients, then one mu_1 scale per chain
+        for (int c = 0; c < nb; ++c) {
+            double m0 = 0.0;
+            for (int k = 0; k < nseed; ++k) {
+                const size_t q = (size_t)c * nseed + k, g = (size_t)(c0 + c) * nseed + k;
+                seeds0[q] = seed_atoms[g] - 1;
+                coef[2 * q] = seed_coef ? seed_coef[2 * g] : 1.0;
+                coef[2 * q + 1] = seed_coef ? seed_coef[2 * g + 1] : 0.0;
+            }
+            // mu_1 = sum over seed atoms of |final coefficient|^2 (later seeds overwrite earlier ones on the same atom)
+            for (int k = 0; k < nseed; ++k) {
+                bool overwritten = false;
+                for (int k2 = k + 1; k2 < nseed; ++k2) overwritten |= seeds0[(size_t)c * nseed + k2] == seeds0[(size_t)c * nseed + k];
+                const size_t q = (size_t)c * nseed + k;
+                if (!overwritten) m0 += coef[2 * q] * coef[2 * q] + coef[2 * q + 1] * coef[2 * q + 1];
+            }
+            coef[(size_t)nb * nseed * 2 + c] = m0;
+        }
         int ostride = kk;
-        rc = upload_regions(h, seeds0.data(), nb, 1, nlev, napply, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
+        rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, napply, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -730,8 +746,8 @@ int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, do
         double* tmp = h->d_vec[3].as<double>();
         double* tmp2 = h->d_vec[4].as<double>();
         const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
-        k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);
-        k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride);                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
+        k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
             const bool first = (t == 1);
@@ -771,7 +787,7 @@ int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, do
             hipEvent_t e1 = next_event(h);
             hop_ev.emplace_back(e0, e1);
             h->n_hop_launch += hoh ? 2 : 1;
-            k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>());
+            k_reduce_cheb<<<nb, 1024, 0, h->stream>>>(h->d_partial.as<double2>(), nblk, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
             if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
         }
         HIPCK(h, hipGetLastError());
@@ -791,17 +807,22 @@ int run_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, do
 
 }  // namespace
 
-extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+extern "C" int rsrec_chebyshev_seeded(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld, double a, double b,
+                                      double* mu_n) {
     int rc = check_ready(h, "rsrec_chebyshev");
     if (rc) return rc;
-    if (nsites < 0 || lld < 1 || !mu_n || (nsites > 0 && !seed_atoms) || a == 0.0) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: bad argument");
-    for (int q = 0; q < nsites; ++q)
+    if (nchains < 0 || nseed < 1 || nseed > 8 || lld < 1 || !mu_n || (nchains > 0 && !seed_atoms) || a == 0.0) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: bad argument");
+    for (int q = 0; q < nchains * nseed; ++q)
         if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
     HIPCK(h, hipSetDevice(h->device));
     reset_timing(h);
-    if (nsites == 0) return RSREC_OK;
-    if (h->opt_kernels != 1) return run_chebyshev<LayoutRM, true>(h, nsites, seed_atoms, lld, a, b, mu_n);
-    return run_chebyshev<LayoutCM, false>(h, nsites, seed_atoms, lld, a, b, mu_n);
+    if (nchains == 0) return RSREC_OK;
+    if (h->opt_kernels != 1) return run_chebyshev<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n);
+    return run_chebyshev<LayoutCM, false>(h, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n);
+}
+
+extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
+    return rsrec_chebyshev_seeded(h, nsites, 1, seed_atoms, nullptr, lld, a, b, mu_n);
 }
 
 extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, int llmax, double* a, double* b2) {

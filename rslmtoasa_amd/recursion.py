@@ -188,25 +188,41 @@ class Recursion:
         pairs = np.asarray(self.lattice.ijpair, dtype=np.int32)
         njij = len(pairs)
         start, end = site_partition(self.rank, self.nprocs, njij)
-        s2 = 1.0 / np.sqrt(2.0)          # one_over_sqrt_two (math.f90)
-        slots, seeds, coefs = [], [], []
-        for ij_loc, (i, j) in enumerate(pairs[start - 1:end]):
-            for reci in range(4):
-                if i == j:
-                    if reci > 0:
-                        continue                                      # :1705-1706 `cycle`: slots 2..4 stay zero
-                    seeds.append((i, i)); coefs.append((1.0, 0.0))    # :1702-1704
-                else:
-                    seeds.append((i, j)); coefs.append((s2, (s2, -s2, 1j * s2, -1j * s2)[reci]))   # :1679-1700
-                slots.append(ij_loc * 4 + reci)                       # ij_loc*4 - 4 + reci (:1721)
-        nch = len(seeds)
-        sa = np.ascontiguousarray(seeds, dtype=np.int32)
-        sc = np.ascontiguousarray(coefs, dtype=np.complex128)
+        slots, sa, sc = self._pair_seeds(pairs[start - 1:end], skip_diagonal_repeats=True)
+        nch = len(slots)
         a_b = np.zeros((18, 18, lld, nch), np.complex128, order="F")
         b2_b = np.zeros_like(a_b)
         self._check(self._L.rsrec_block_lanczos_seeded(self._h, nch, 2, _ptr(sa), _ptr(sc), lld, _ptr(a_b), _ptr(b2_b)))
         self.a_b[:, :, :, slots] = a_b
         self.b2_b[:, :, :, slots] = b2_b
+
+    @staticmethod
+    def _pair_seeds(pairs, skip_diagonal_repeats):
+        """(asign, bsign) of the four chains of every pair (recursion.f90:1679-1707 / :2403-2448); slot = ij_loc*4 - 4 + reci."""
+        s2 = 1.0 / np.sqrt(2.0)          # one_over_sqrt_two (math.f90)
+        slots, seeds, coefs = [], [], []
+        for ij_loc, (i, j) in enumerate(pairs):
+            for reci in range(4):
+                a, b = s2, (s2, -s2, 1j * s2, -1j * s2)[reci]
+                if i == j and skip_diagonal_repeats:
+                    if reci > 0:
+                        continue                                      # recur_b_ij :1705-1706 `cycle`: slots 2..4 stay zero
+                    a = b = 1.0                                       # :1702-1704
+                seeds.append((i, j)); coefs.append((a, b))            # assigned in order: for i == j the second value stays
+                slots.append(ij_loc * 4 + reci)
+        return slots, np.ascontiguousarray(seeds, dtype=np.int32), np.ascontiguousarray(coefs, dtype=np.complex128)
+
+    def chebyshev_recur_ij(self):
+        """Chebyshev moments of the four chains per pair (recursion.f90:2376-2487); no i == j special case there."""
+        lld = self.control.lld
+        a, b = chebyshev_scaling(self.en.energy_min, self.en.energy_max)
+        pairs = np.asarray(self.lattice.ijpair, dtype=np.int32)
+        start, end = site_partition(self.rank, self.nprocs, len(pairs))
+        slots, sa, sc = self._pair_seeds(pairs[start - 1:end], skip_diagonal_repeats=False)
+        nch = len(slots)
+        mu = np.zeros((18, 18, 2 * lld + 2, nch), np.complex128, order="F")
+        self._check(self._L.rsrec_chebyshev_seeded(self._h, nch, 2, _ptr(sa), _ptr(sc), lld, a, b, _ptr(mu)))
+        self.mu_n[:, :, :, slots] = mu
 
     def zsqr(self):
         """b2_b <- sqrt(b2_b) in place (recursion.f90:1980-2023)."""

@@ -13,6 +13,7 @@ BLOCK_CASES = ["bccFe_nsp2_block", "bccFe_nsp2_block_hoh", "bccFe_nsp4_block", "
 CHEB_CASES = ["bccFe_nsp2_cheb", "bccFe_nsp2_cheb_hoh", "fccCu001_cheb"]
 SCALAR_CASES = ["bccFe_nsp1_lanczos"]
 SUPERCELL_CASES = ["sc_4x4x8_block", "sc_4x4x8_block_hoh", "sc_4x4x8_cheb", "sc_22_block"]
+PAIR_CASES = ["sc_4x4x8_block_ij", "sc_4x4x8_cheb_ij", "sc_4x4x8_cheb_ij_hoh"]
 
 # Parity bar of BASELINE.json: 1e-10 relative on recursion coefficients / moments.
 RTOL = 1e-10

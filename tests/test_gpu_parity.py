@@ -6,7 +6,7 @@ All arithmetic is FP64; differences come only from summation order (MFMA / tree 
 import numpy as np
 import pytest
 
-from helpers import (BLOCK_CASES, CHEB_CASES, RTOL, SCALAR_CASES, load_golden, objects_from, problem_dict, rel_err, supercell_problem)
+from helpers import (BLOCK_CASES, CHEB_CASES, PAIR_CASES, RTOL, SCALAR_CASES, load_golden, objects_from, problem_dict, rel_err, supercell_problem)
 from rslmtoasa_amd.lattice import spread_sites
 from rslmtoasa_amd.recursion import Recursion
 
@@ -41,10 +41,12 @@ def test_block_lanczos_golden(name, kernels, oracle_lib):
     rec.close()
 
 
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("name", CHEB_CASES)
-def test_chebyshev_golden(name):
+def test_chebyshev_golden(name, kernels):
     g = load_golden(name)
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], emin=g["emin"], emax=g["emax"])
+    rec.set_option("kernels", kernels)
     rec.chebyshev_recur()
     assert rel_err(rec.mu_n[:, :, :, : g["nrec"]], g["mu_n"]) < RTOL
     rec.close()
@@ -141,24 +143,23 @@ def test_batching_is_invisible():
     rec.close()
 
 
-def test_pair_seeds_recur_b_ij(oracle_lib):
-    """Four chains per pair (recursion.f90:1655-1737): checked through linearity against single-site chains.
-    For i == j only the first slot is filled (:1702-1707)."""
-    g = load_golden("bccFe_nsp2_block")
-    p = problem_dict(g)
-    ham, lat, ctl, en = objects_from(p, g["irec"], 8)
-    i = int(g["irec"][0]); j = int(p["nn"][i - 1, 1])
-    lat.ijpair = np.array([[i, j], [i, i]], dtype=np.int32)
+@pytest.mark.parametrize("kernels", KERNELS)
+@pytest.mark.parametrize("name", PAIR_CASES)
+def test_pair_variants_golden(name, kernels):
+    """recur_b_ij / chebyshev_recur_ij (recursion.f90:1655 / :2376): four chains per pair, against the compiled reference."""
+    g = load_golden(name)
+    p = supercell_problem(g["dims"], hoh=bool(g["hoh"]))
+    ham, lat, ctl, en = objects_from(p, [1], int(g["lld"]), emin=float(g["emin"]), emax=float(g["emax"]))
+    lat.ijpair = np.asarray(g["pairs"], dtype=np.int32)
     rec = Recursion(ham, lat, ctl, en)
-    rec.recur_b_ij()
-    # slot 5 (pair i==i, reci=1) equals the plain site chain; slots 6..8 untouched
-    o = oracle_lib.Oracle(p)
-    a_o, b_o = o.block_lanczos(np.array([i], np.int32), 8)
-    assert rel_err(rec.a_b[:, :, :, 4], a_o[:, :, :, 0]) < RTOL
-    assert np.all(rec.a_b[:, :, :, 5:8] == 0)
-    # A_1 of the four (i,j) chains: <s|H|s> with s = (|i> + c|j>)/sqrt2 = (H_ii + |c|^2 H_jj + c H_ij + conj(c) H_ji)/2
-    a1 = rec.a_b[:, :, 0, :4]
-    assert rel_err(a1[:, :, 0] + a1[:, :, 1], a1[:, :, 2] + a1[:, :, 3]) < 1e-12
+    rec.set_option("kernels", kernels)
+    if "cheb" in name:
+        rec.chebyshev_recur_ij()
+        assert rel_err(rec.mu_n, g["mu_n"]) < RTOL
+    else:
+        rec.recur_b_ij()
+        assert rel_err(rec.a_b, g["a_b"]) < RTOL and rel_err(rec.b2_b, g["b2_b"]) < RTOL
+        assert np.all(rec.a_b[:, :, :, 5:8] == 0)          # pair (7,7): slots 2..4 untouched (:1705-1706)
     rec.close()
 
 
