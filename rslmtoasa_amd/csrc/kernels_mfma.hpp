@@ -141,8 +141,12 @@ __device__ __forceinline__ RowRef group_row(const int* __restrict__ grp, int rho
 }
 
 // ---- K3: psi_i <- pmn_i * Binv ; pmn_i <- psi_i * B  (crecal_b :1963-1969) --------------------------------------------
+// HALF = true ("three-term" scheme): only psi_next = pmn * Binv is formed and written to `psi` (which then holds the buffer of
+// psi_{n-1}, dead by now); pmn_next = psi_n * B is never materialised -- the next level's orthogonalisation subtracts
+// psi_{n-1} * B_n on the fly (k_mfma_orth<2>).  Saves one block read and one block write per atom-step.
+template <bool HALF>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_update(ChainView CV, int level, int zero_block, double* psi, double* pmn,
-                                                                 const double* __restrict__ bfrags /*[chain][2][27*64]: B, Binv*/) {
+                                                                 const double* __restrict__ bfrags /*[chain][3][27*64]: B, Binv, -B*/) {
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -152,20 +156,20 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_update(ChainView CV, 
     double* ps = psi + vo;
     double* pm = pmn + vo;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
-    double gB[27], gBi[27];
+    double gB[HALF ? 1 : 27], gBi[27];
     {
-        const double* fb = bfrags + (size_t)chain * 2 * 27 * 64 + lane;
+        const double* fb = bfrags + (size_t)chain * 3 * 27 * 64 + lane;
 #pragma unroll
-        for (int e = 0; e < 27; ++e) { gB[e] = fb[e * 64]; gBi[e] = fb[(27 + e) * 64]; }
+        for (int e = 0; e < 27; ++e) { if (!HALF) gB[e] = fb[e * 64]; gBi[e] = fb[(27 + e) * 64]; }
     }
     for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
 #pragma unroll 1
         for (int mt = 0; mt < 9; ++mt) {
             const RowRef ra = group_row(grp, 16 * mt + l15, zero_block);           // A-operand row of this lane
-            double a1[9], a2[9];
+            double a1[9], a2[HALF ? 1 : 9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) { a1[q] = pm[ra.off + 4 * q + l4]; a2[q] = ps[ra.off + 4 * q + l4]; }
+            for (int q = 0; q < 9; ++q) { a1[q] = pm[ra.off + 4 * q + l4]; if (!HALF) a2[q] = ps[ra.off + 4 * q + l4]; }
             double4_t y1a = {0, 0, 0, 0}, y1b = {0, 0, 0, 0}, y2a = {0, 0, 0, 0}, y2b = {0, 0, 0, 0};
             double y1r = 0.0, y2r = 0.0;
 #pragma unroll
@@ -173,20 +177,22 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_update(ChainView CV, 
                 y1a = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], gBi[3 * q + 0], y1a, 0, 0, 0);
                 y1b = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], gBi[3 * q + 1], y1b, 0, 0, 0);
                 y1r = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[q], gBi[3 * q + 2], y1r, 0, 0, 0);
-                y2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 0], y2a, 0, 0, 0);
-                y2b = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 1], y2b, 0, 0, 0);
-                y2r = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[q], gB[3 * q + 2], y2r, 0, 0, 0);
+                if (!HALF) {
+                    y2a = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 0], y2a, 0, 0, 0);
+                    y2b = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], gB[3 * q + 1], y2b, 0, 0, 0);
+                    y2r = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[q], gB[3 * q + 2], y2r, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
                 if (rs.valid) {
                     ps[rs.off + l15] = y1a[j]; ps[rs.off + 16 + l15] = y1b[j];
-                    pm[rs.off + l15] = y2a[j]; pm[rs.off + 16 + l15] = y2b[j];
+                    if (!HALF) { pm[rs.off + l15] = y2a[j]; pm[rs.off + 16 + l15] = y2b[j]; }
                 }
             }
             const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);    // 4x4x4 D: row 4g + i, column 32 + j
-            if (rr.valid) { ps[rr.off + 32 + l3] = y1r; pm[rr.off + 32 + l3] = y2r; }
+            if (rr.valid) { ps[rr.off + 32 + l3] = y1r; if (!HALF) pm[rr.off + 32 + l3] = y2r; }
         }
     }
 }
@@ -274,10 +280,15 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
 }
 
 // ---- K2: pmn_i <- (t_i - pmn_i) - psi_i * A ; Gm += pmnhat^T pmnhat   (hop_b :1641, crecal_b :1922-1934) ----------------
-template <bool HAS_T>
+// MODE 0: pmn <- pmn - psi A                      (pmn already holds H psi - pmn_old: VALU/fused epilogues)
+// MODE 1: pmn <- (t - pmn) - psi A                (t = H psi from the SpMM kernel)
+// MODE 2: pmn <- t - psi_prev B_n - psi A         (three-term scheme: pmn_old = psi_prev B_n is formed here, never stored)
+template <int MODE>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, int level, int zero_block, const double* __restrict__ psi, double* pmn,
                                                                const double* __restrict__ tvec, const double* __restrict__ afrags /*[chain][27*64] = -A*/,
-                                                               double* partial /*[chain][nblk][1296]*/) {
+                                                               double* partial /*[chain][nblk][1296]*/, const double* __restrict__ psi_prev = nullptr,
+                                                               const double* __restrict__ bfrags = nullptr /*[chain][3][27*64], third = -B_n*/) {
+    constexpr bool HAS_T = MODE != 0;
     __shared__ double lds[MF_WAVES * 1296];
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -289,11 +300,17 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
     const double* tv = HAS_T ? tvec + vo : nullptr;
     double* pm = pmn + vo;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
-    double nA[27];
+    const double* pp = (MODE == 2) ? psi_prev + vo : nullptr;
+    double nA[27], nB[MODE == 2 ? 27 : 1];
     {
         const double* fa = afrags + (size_t)chain * 27 * 64 + lane;
 #pragma unroll
         for (int e = 0; e < 27; ++e) nA[e] = fa[e * 64];
+        if (MODE == 2) {
+            const double* fb = bfrags + ((size_t)chain * 3 + 2) * 27 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 27; ++e) nB[e] = fb[e * 64];
+        }
     }
     GramAcc Gm;
     Gm.zero();
@@ -302,16 +319,19 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
 #pragma unroll 1
         for (int mt = 0; mt < 9; ++mt) {
             const RowRef ra = group_row(grp, 16 * mt + l15, zero_block);
-            double a[9];
+            double a[9], ap[MODE == 2 ? 9 : 1];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) a[q] = ps[ra.off + 4 * q + l4];
-            // C = t - pmn in D layout
+            for (int q = 0; q < 9; ++q) { a[q] = ps[ra.off + 4 * q + l4]; if (MODE == 2) ap[q] = pp[ra.off + 4 * q + l4]; }
+            // C in D layout
             RowRef rs[4];
             double4_t ca, cb;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 rs[j] = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
-                if (HAS_T) {
+                if (MODE == 2) {
+                    ca[j] = tv[rs[j].off + l15];
+                    cb[j] = tv[rs[j].off + 16 + l15];
+                } else if (MODE == 1) {
                     ca[j] = tv[rs[j].off + l15] - pm[rs[j].off + l15];
                     cb[j] = tv[rs[j].off + 16 + l15] - pm[rs[j].off + 16 + l15];
                 } else {
@@ -320,7 +340,15 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
                 }
             }
             const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
-            double cr = HAS_T ? tv[rr.off + 32 + l3] - pm[rr.off + 32 + l3] : pm[rr.off + 32 + l3];
+            double cr = (MODE == 2) ? tv[rr.off + 32 + l3] : (MODE == 1 ? tv[rr.off + 32 + l3] - pm[rr.off + 32 + l3] : pm[rr.off + 32 + l3]);
+            if (MODE == 2) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {       // - psi_prev * B_n first (the reference subtracts pmn_old before psi A)
+                    ca = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[q], nB[3 * q + 0], ca, 0, 0, 0);
+                    cb = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[q], nB[3 * q + 1], cb, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[q], nB[3 * q + 2], cr, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nA[3 * q + 0], ca, 0, 0, 0);
@@ -585,7 +613,8 @@ __global__ __launch_bounds__(1024) void k_reduce_b_eig_mf(const double* __restri
         matfun18(sh, which ? sh.f2 : sh.f1, Bm);                                   // into LDS
         __syncthreads();
         for (int e = threadIdx.x; e < BLK; e += blockDim.x) Bout[which * BLK + e] = Bm[e];
-        emit_rhs_frags(Bm, 1.0, bfrags + ((size_t)chain * 2 + which) * 27 * 64);
+        emit_rhs_frags(Bm, 1.0, bfrags + ((size_t)chain * 3 + which) * 27 * 64);
+        if (which == 0) emit_rhs_frags(Bm, -1.0, bfrags + ((size_t)chain * 3 + 2) * 27 * 64);   // -B_{n+1} for the next level (three-term scheme)
         __syncthreads();
     }
 }

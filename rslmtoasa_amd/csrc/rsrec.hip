@@ -63,7 +63,7 @@ struct rsrec_handle {
     // work
     DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_fuse = 0;   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 1, opt_fuse = 0;   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -203,6 +203,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "wps")) h->opt_wps = value;
     else if (!strcmp(key, "post")) h->opt_post = value;
     else if (!strcmp(key, "fuse")) h->opt_fuse = value;
+    else if (!strcmp(key, "three_term")) h->opt_three = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -482,14 +483,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int nsteps = lld - 1;
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
-    const int nvec = MFMA ? (hoh ? 4 : 3) : (hoh ? 3 : 2);
+    const int nvec = MFMA ? 4 : (hoh ? 3 : 2);
+    const bool three_term = MFMA && !hoh && h->opt_post != 1 && !h->opt_fuse && h->opt_three;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2)));
-    HIPCK(h, h->d_frags.reserve((size_t)B * 3 * 27 * 64 * sizeof(double)));
+    HIPCK(h, h->d_frags.reserve((size_t)B * 4 * 27 * 64 * sizeof(double)));
     HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_bmats.reserve((size_t)B * 2 * BLK * sizeof(double2)));
@@ -539,6 +541,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
+        if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
+        psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (the three-term scheme swaps them every level)
         k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
         const dim3 grid(nblk, nb);
@@ -560,10 +564,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         else k_mfma_spmm<1, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, pmn, gpartial);
                         e1 = next_event(h);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
-                        k_mfma_orth<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
+                        k_mfma_orth<0><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
                         k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                        h->d_status.as<int>());
-                        k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                        k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
                         hop_ev.emplace_back(e0, e1);
                         h->n_hop_launch += 1;
                         continue;
@@ -575,10 +579,19 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     if (mf_post) {
                         k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
-                        k_mfma_orth<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
-                        k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                       h->d_status.as<int>());
-                        k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                        if (three_term) {
+                            // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
+                            k_mfma_orth<2><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial, t2, bfrags);
+                            k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                           h->d_status.as<int>());
+                            k_mfma_update<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, t2, pmn, bfrags);
+                            std::swap(psi, t2);
+                        } else {
+                            k_mfma_orth<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
+                            k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                           h->d_status.as<int>());
+                            k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                        }
                         hop_ev.emplace_back(e0, e1);
                         h->n_hop_launch += 1;
                         continue;
@@ -601,10 +614,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 G.in = t2; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
                 k_apply<AM_HOH_LANCZOS, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 k_reduce_a_c2f<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride, afrags);
-                k_mfma_orth<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
+                k_mfma_orth<0><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
                 k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                h->d_status.as<int>());
-                k_mfma_update<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
+                k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += 2;
                 continue;
