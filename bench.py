@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from rslmtoasa_amd.lattice import bcc_supercell, spread_sites  # noqa: E402
+from rslmtoasa_amd.lattice import bcc_supercell, spread_sites, supercell_positions  # noqa: E402
 from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); rate measured here: profiles/ubench_f64_r01.txt
@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--lld", type=int, default=50)
     ap.add_argument("--kernels", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--spmm4", type=int, default=-1, help="SpMM kernel: 0 = 16x16x4 MFMA, 1 = 4x4x4 MFMA one wave per group, 4 = 4x4x4 cooperative; -1 = library default")
+    ap.add_argument("--no-positions", action="store_true", help="do not pass atom positions (locality hint)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -117,7 +119,7 @@ def main():
     kk = nn.shape[0]
     nsites_total = args.sites * world
     irec = spread_sites(kk, nsites_total)
-    lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1)
+    lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1, cr=None if args.no_positions else supercell_positions((n, n, n)))
     ham = Hamiltonian(ee=ee, lsham=lsham, hoh=False)
     ctl = Control(lld=args.lld, nsp=2, recur="block")
     rec = Recursion(ham, lat, ctl, Energy(), device=local_rank, rank=rank, nprocs=world)   # uploads tables: resident before timing
@@ -125,6 +127,8 @@ def main():
         rec.set_option("kernels", args.kernels)
     if args.batch:
         rec.set_option("batch", args.batch)
+    if args.spmm4 >= 0:
+        rec.set_option("spmm4", args.spmm4)
 
     from rslmtoasa_amd.parallel import allgather_sites
 

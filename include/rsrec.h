@@ -55,6 +55,12 @@ int rsrec_destroy(rsrec_t *h);
  *   nmax: the first nmax atoms carry per-atom blocks `hall` (impurity region), 0 for bulk/surface */
 int rsrec_set_lattice(rsrec_t *h, int kk, int nncols, const int32_t *nn, const int32_t *iz, int nmax, int ntype);
 
+/* OPTIONAL locality hint: Cartesian atom positions, lattice%cr(3,kk) (lattice.f90:138-239), any unit.  The recursion's
+ * arithmetic never reads them; they only decide the ORDER in which atoms are processed so that neighbouring atoms share
+ * their psi-block gathers in L2.  Without the hint an ordering is derived from graph distances.  Results do not depend on it
+ * beyond summation order of the reductions. */
+int rsrec_set_positions(rsrec_t *h, const double *cr);
+
 /* Operator blocks read by the recursion: hamiltonian%ee, %lsham, %eeo, %enim, %hall, %hallo
  * (hamiltonian.f90:51-64, shapes :290-301).  Must be called again whenever the caller rebuilt them
  * (self.f90:777-797 rebuilds before every recur* call).

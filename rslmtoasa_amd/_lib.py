@@ -19,6 +19,7 @@ _SIGNATURES = {
     "rsrec_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "rsrec_destroy": (C.c_int, [C.c_void_p]),
     "rsrec_set_lattice": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rsrec_set_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrec_set_hamiltonian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "rsrec_block_lanczos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

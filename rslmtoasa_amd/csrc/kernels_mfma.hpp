@@ -151,7 +151,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_update(ChainView CV, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = CV.count_of(chain, level) / GROUP;
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     double* ps = psi + vo;
     double* pm = pmn + vo;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = CV.count_of(chain, level) / GROUP;
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     const double* ps = psi + vo;
     const double* tv = tvec + vo;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = CV.count_of(chain, level) / GROUP;
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     const double* ps = psi + vo;
     const double* tv = HAS_T ? tvec + vo : nullptr;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }
 
-struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; };
+struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; const int* obase; };
 
 // All pointers are separate __restrict__ kernel parameters: only `out` is written, so hipcc can prove the index tables
 // read-only and fetch them with scalar loads (they then never enter the vmcnt queue the operand prefetch relies on).
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, WPS) void k_mfma_spmm(SpmmDims D, co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: group bookkeeping lives in SGPRs
     const int count = cum[(chain / D.cpo) * D.nlev + D.level];           // multiple of GROUP
     const int ngroups = count / GROUP;
-    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride;
+    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
     const size_t vo = (size_t)chain * D.vstride;
     const double* __restrict__ in = in_all + vo;
     double* __restrict__ out = out_all + vo;

@@ -45,11 +45,13 @@ struct DevProblem {
 struct ChainView {           // per launch: a batch of chains with identical strides
     const int* order;        // [nchain][ostride], entries < 0 are padding
     const int* cum;          // [nchain][nlev]
+    const int* obase;        // [nchain][nlev] start of the list to use at a level inside the order row (0 = level-major list;
+                             //   levels at which the region is (nearly) the whole lattice point at a spatially sorted list of ALL atoms)
     int nlev;
     size_t vstride;          // doubles between chains in a work vector = (kk+1)*648 (last block is an all-zero block)
     int cpo;                 // chains sharing one order/cum row (1; 18 for the scalar recursion's orbital chains)
     int ostride;             // entries per order row (kk, or more when the list is padded into type-homogeneous groups of 8)
-    __device__ __forceinline__ const int* order_of(int chain) const { return order + (size_t)(chain / cpo) * ostride; }
+    __device__ __forceinline__ const int* order_of(int chain, int level) const { return order + (size_t)(chain / cpo) * ostride + obase[(chain / cpo) * nlev + level]; }
     __device__ __forceinline__ int count_of(int chain, int level) const { return cum[(chain / cpo) * nlev + level]; }
 };
 
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void k_apply(DevProblem P, ChainView CV, 
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, c = threadIdx.x % NB;
     const int count = CV.count_of(chain, G.level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, G.level);
     const size_t vo = (size_t)chain * CV.vstride;
     const double* in = G.in + vo;
     constexpr bool second_pass = (MODE == AM_HOH_LANCZOS || MODE == AM_HOH_CHEB1 || MODE == AM_HOH_CHEBN);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(NTHREADS) void k_adot(ChainView CV, int level, cons
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, c = threadIdx.x % NB;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     double2 part[NB];
 #pragma unroll
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS) void k_orth(ChainView CV, int level, cons
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, r = threadIdx.x % NB;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     for (int e = threadIdx.x; e < BLK; e += blockDim.x) As[e] = Amat[chain * astride + e];
     double2 part[NB];
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NTHREADS) void k_update(ChainView CV, int level, do
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, r = threadIdx.x % NB;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     for (int e = threadIdx.x; e < BLK; e += blockDim.x) { Bs[e] = Bmats[(size_t)chain * 2 * BLK + e]; Bis[e] = Bmats[(size_t)chain * 2 * BLK + BLK + e]; }
     __syncthreads();
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scalar_hop(DevProblem P, ChainView
     const int chain = blockIdx.y;
     const int a = threadIdx.x / NB, r = threadIdx.x % NB;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     double asum = 0.0;
     for (int tile = blockIdx.x; tile * TILE_ATOMS < count; tile += gridDim.x) {
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scalar_orth(int kk, ChainView CV, 
     __shared__ double red[NTHREADS];
     const int chain = blockIdx.y;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     const double an = acoef[chain * astride + ll];
     double s2 = 0.0;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scalar_orth(int kk, ChainView CV, 
 __global__ __launch_bounds__(NTHREADS) void k_scalar_update(int kk, ChainView CV, int level, double2* psi, double2* pmn, const double* __restrict__ b2coef, size_t bstride, int ll) {
     const int chain = blockIdx.y;
     const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain);
+    const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
     const double summ = b2coef[chain * bstride + ll + 1];
     const double sinv = 1.0 / sqrt(summ), sq = sqrt(summ);

@@ -24,6 +24,7 @@
 #include "../../include/rsrec.h"
 #include "kernels_valu.hpp"
 #include "kernels_mfma.hpp"
+#include "kernels_spmm4.hpp"
 
 using namespace rsrec;
 
@@ -60,10 +61,12 @@ struct rsrec_handle {
     int hslots = 0, hoh = 0, nsp = 2;
     DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
     MfmaOperator mfma_op;
+    Spmm4Operator s4_op;
+    int s4_built_split = 0;
     // work
     DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 1, opt_fuse = 0;   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 1, opt_spmm4 = -1, opt_fuse = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -81,7 +84,9 @@ struct rsrec_handle {
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
     const int* cur_order = nullptr;
-    const int* cur_cum = nullptr;
+    const int* cur_cum = nullptr;     // [nrows][nlev] counts, followed by [nrows][nlev] list offsets
+    int cur_nrows = 0;
+    std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
 };
 
 namespace {
@@ -150,6 +155,54 @@ void grow_region(const rsrec_t* h, const int* seeds, int nseed, int nlev, Region
 
 }  // namespace
 
+namespace {
+
+inline unsigned spread3(unsigned v) {           // 10 bits -> every third bit
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+inline unsigned morton3(unsigned x, unsigned y, unsigned z) { return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2); }
+
+// breadth-first distances over the (symmetrised) neighbour graph from one atom
+void bfs_dist(const rsrec_t* h, int start, std::vector<int>& dist) {
+    const int kk = h->kk, ns = h->nslots;
+    dist.assign(kk, -1);
+    std::vector<int> cur{start}, nxt;
+    dist[start] = 0;
+    int d = 0;
+    while (!cur.empty()) {
+        nxt.clear();
+        for (int n : cur) {
+            for (int j = 1; j < ns; ++j) { const int i = h->nbr[(size_t)n * ns + j]; if (i >= 0 && dist[i] < 0) { dist[i] = d + 1; nxt.push_back(i); } }
+            for (int q = h->radj_ptr[n]; q < h->radj_ptr[n + 1]; ++q) { const int i = h->radj[q]; if (dist[i] < 0) { dist[i] = d + 1; nxt.push_back(i); } }
+        }
+        cur.swap(nxt);
+        ++d;
+    }
+}
+
+// Locality hint when the caller gives no coordinates: graph distances to three far-apart landmark atoms act as
+// pseudo-coordinates (adequate for ordering: atoms with similar distance triples are close in the lattice).
+void spatial_key_from_graph(rsrec_t* h) {
+    const int kk = h->kk;
+    std::vector<int> d0, d1, d2;
+    bfs_dist(h, 0, d0);
+    int l1 = 0;
+    for (int i = 0; i < kk; ++i) if (d0[i] >= d0[l1]) l1 = i;
+    bfs_dist(h, l1, d1);
+    int l2 = 0, best = -1;
+    for (int i = 0; i < kk; ++i) { const int m = std::min(d0[i], d1[i]); if (m >= best) { best = m; l2 = i; } }
+    bfs_dist(h, l2, d2);
+    h->spatial_key.resize(kk);
+    for (int i = 0; i < kk; ++i) h->spatial_key[i] = morton3((unsigned)std::max(d0[i], 0), (unsigned)std::max(d1[i], 0), (unsigned)std::max(d2[i], 0));
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int rsrec_version(void) { return 100; }
 
@@ -184,6 +237,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     for (auto b : all) b->release();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->mfma_op.release();
+    h->s4_op.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return RSREC_OK;
@@ -204,6 +258,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "post")) h->opt_post = value;
     else if (!strcmp(key, "fuse")) h->opt_fuse = value;
     else if (!strcmp(key, "three_term")) h->opt_three = value;
+    else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -265,9 +320,29 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
     HIPCK(h, h->d_iz.reserve((size_t)kk * sizeof(int)));
     HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
+    spatial_key_from_graph(h);
     h->have_lattice = true;
     h->lattice_epoch++;
     h->have_ham = false;   // operator tables depend on nmax/ntype: must be set again
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_set_positions(rsrec_t* h, const double* cr) {
+    if (!h || !cr) return fail(h, RSREC_ERR_ARG, "rsrec_set_positions: bad argument");
+    if (!h->have_lattice) return fail(h, RSREC_ERR_ARG, "rsrec_set_positions: call rsrec_set_lattice first");
+    const int kk = h->kk;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < kk; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], cr[3 * (size_t)i + a]); hi[a] = std::max(hi[a], cr[3 * (size_t)i + a]); }
+    double span = 1e-300;
+    for (int a = 0; a < 3; ++a) span = std::max(span, hi[a] - lo[a]);
+    h->spatial_key.resize(kk);
+    for (int i = 0; i < kk; ++i) {
+        unsigned q[3];
+        for (int a = 0; a < 3; ++a) q[a] = (unsigned)std::min(1023.0, std::max(0.0, (cr[3 * (size_t)i + a] - lo[a]) / span * 1023.0));
+        h->spatial_key[i] = morton3(q[0], q[1], q[2]);
+    }
+    h->lattice_epoch++;        // cached region orders were built with the old keys
     return RSREC_OK;
 }
 
@@ -315,6 +390,13 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
         const char* msg = h->mfma_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
                                            (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham);
         if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
+        if (h->nslots <= S4_MAXSLOTS) {
+            const int nsplit = 1;
+            msg = h->s4_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
+                                 (hoh && nmax > 0) ? hallo : nullptr, nsplit);
+            if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
+            h->s4_built_split = nsplit;
+        }
     }
     h->have_ham = true;
     return RSREC_OK;
@@ -362,41 +444,61 @@ int plan_batch(rsrec_t* h, int nchains, int nvec, size_t vec_elems_per_chain, Ba
 int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, int napply, bool two_pass, bool grouped, int& ostride,
                    double& atom_steps, double& block_mults) {
     const int kk = h->kk;
-    ostride = grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk;
+    // order row = [level-major list | spatially sorted list of ALL atoms]; each list padded into operator-class groups of 8 when grouped
+    const int cap = grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk;
+    ostride = 2 * cap;
     const int flags = (two_pass ? 1 : 0) | (grouped ? 2 : 0) | (nseed << 2);
     for (auto* e : h->region_cache)
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
-            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>();
+            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
-    std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)nb * nlev);
+    std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)2 * nb * nlev, 0);
     std::vector<double> as(nb, 0.0), bm(nb, 0.0);
+    auto tau = [&](int i) { return i < h->nmax ? i : h->nmax + h->iz0[i]; };
+    const std::vector<unsigned>& key = h->spatial_key;
+    auto before = [&](int x, int y) {                       // operator class first (groups must be homogeneous), then position
+        const int tx = grouped ? tau(x) : 0, ty = grouped ? tau(y) : 0;
+        if (tx != ty) return tx < ty;
+        if (key[x] != key[y]) return key[x] < key[y];
+        return x < y;
+    };
+    // the list of all atoms is the same for every chain of the lattice
+    std::vector<int> all(kk), sat_list;
+    for (int i = 0; i < kk; ++i) all[i] = i;
+    std::sort(all.begin(), all.end(), before);
+    sat_list.reserve(cap);
+    for (int q = 0; q < kk; ++q) {
+        if (grouped && q > 0 && tau(all[q]) != tau(all[q - 1])) while (sat_list.size() % GROUP) sat_list.push_back(-1);
+        sat_list.push_back(all[q]);
+    }
+    if (grouped) while (sat_list.size() % GROUP) sat_list.push_back(-1);
+    const int sat_count = (int)sat_list.size();
 #pragma omp parallel for schedule(dynamic, 1)
     for (int c = 0; c < nb; ++c) {
         Region R;
         grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, R);
         int* orow = order.data() + (size_t)c * ostride;
         int* crow = cum.data() + (size_t)c * nlev;
-        if (!grouped) {
-            std::copy(R.order.begin(), R.order.end(), orow);
-            std::copy(R.cum.begin(), R.cum.end(), crow);
-        } else {
-            auto tau = [&](int i) { return i < h->nmax ? i : h->nmax + h->iz0[i]; };
-            int w = 0;
-            std::vector<int> lev;
-            for (int L = 0; L < nlev; ++L) {
-                const int lo = L ? R.cum[L - 1] : 0, hi = R.cum[L];
-                lev.assign(R.order.begin() + lo, R.order.begin() + hi);
-                std::stable_sort(lev.begin(), lev.end(), [&](int x, int y) { return tau(x) < tau(y); });
-                for (size_t q = 0; q < lev.size(); ++q) {
-                    if (q > 0 && tau(lev[q]) != tau(lev[q - 1])) while (w % GROUP) orow[w++] = -1;
-                    orow[w++] = lev[q];
-                }
-                while (w % GROUP) orow[w++] = -1;
-                crow[L] = w;
+        int* brow = cum.data() + (size_t)(nb + c) * nlev;
+        std::copy(sat_list.begin(), sat_list.end(), orow + cap);
+        int w = 0;
+        std::vector<int> lev;
+        for (int L = 0; L < nlev; ++L) {
+            const int lo = L ? R.cum[L - 1] : 0, hi = R.cum[L];
+            lev.assign(R.order.begin() + lo, R.order.begin() + hi);
+            std::sort(lev.begin(), lev.end(), before);
+            for (size_t q = 0; q < lev.size(); ++q) {
+                if (grouped && q > 0 && tau(lev[q]) != tau(lev[q - 1])) while (w % GROUP) orow[w++] = -1;
+                orow[w++] = lev[q];
             }
+            if (grouped) while (w % GROUP) orow[w++] = -1;
+            // once the region covers most of the lattice the spatially sorted list of all atoms is used instead: blocks outside
+            // the region are exactly zero, so a superset changes nothing, and neighbouring groups then share their gathers in L2
+            if (R.cum[L] >= (int)(0.8 * kk)) { crow[L] = sat_count; brow[L] = cap; }
+            else { crow[L] = w; brow[L] = 0; }
         }
         // bookkeeping in the reference's terms: application t (1..napply) multiplies one block per (atom, slot) whose
         // source atom lies in the region before it; post-hop work runs on the region after it.
@@ -448,7 +550,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     HIPCK(h, hipMemcpyAsync(e->order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync(e->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
-    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>();
+    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb;
     return RSREC_OK;
 }
 
@@ -474,6 +576,31 @@ int check_ready(rsrec_t* h, const char* who) {
 
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
+
+// store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
+int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
+    if (h->opt_spmm4 != 0 && h->s4_built_split) {
+        // auto: cooperative (4 waves per group) when there are too few groups to give every wave its own -- it also has the
+        // lowest fabric traffic; one wave per group when the launch is large (its per-group overheads amortise better)
+        const long groups_max = (long)grid_mf.y * (h->kk / GROUP + 1);
+        const bool coop = h->opt_spmm4 == 4 || (h->opt_spmm4 < 0 && groups_max < 4096);
+        if (coop) {
+            static bool attr = false;
+            if (!attr) {
+                HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS_BYTES));
+                attr = true;
+            }
+            // one group per workgroup at a time: 4x as many workgroups keep the same number of groups in flight per launch
+            dim3 g4(std::min<unsigned>(grid_mf.x * 4, 1024), grid_mf.y);
+            k_spmm4<4><<<g4, MF_WAVES * 64, S4_LDS_BYTES, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
+        } else {
+            k_spmm4<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
+        }
+    } else {
+        k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(set), in, out, nullptr);
+    }
+    return RSREC_OK;
+}
 
 // One implementation for both kernel sets: L = LayoutCM with the VALU kernels, LayoutRM with the MFMA SpMM.
 template <class L, bool MFMA>
@@ -537,7 +664,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
 
         ChainView CV;
-        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
@@ -556,7 +683,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             G.partial = partial;
             if (!hoh) {
                 if (MFMA) {
-                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems};
+                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
                     const double* frag = h->mfma_op.set_ptr(0);
                     if (mf_post && h->opt_fuse) {
                         // fused hop_b: pmn <- H psi - pmn and the A_n partial inside the SpMM kernel
@@ -573,7 +700,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
+                    else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
                     if (mf_post) {
@@ -604,12 +731,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 }
             } else if (MFMA) {
                 // hoh on the matrix cores: t1 = h psi, t2 = (h o) t1, then the per-atom combine/epilogue (VALU) and MFMA orth/update
-                const double* f0 = h->mfma_op.set_ptr(0);
-                const double* f1 = h->mfma_op.set_ptr(1);
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems};
-                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, f0, psi, hpsi, nullptr);
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
+                rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc;
                 SD.level = lv_final;
-                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, f1, hpsi, t2, nullptr);
+                rc = launch_spmm(h, SD, CV, P, 1, hpsi, t2, grid_mf); if (rc) return rc;
                 e1 = next_event(h);
                 G.in = t2; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
                 k_apply<AM_HOH_LANCZOS, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
@@ -750,7 +875,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         ChainView CV;
-        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
         double* p0 = h->d_vec[0].as<double>();
@@ -772,11 +897,11 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             double* src = first ? p0 : p1;
             double* dst = first ? p1 : p2;
             if (MFMA) {
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems};
-                k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(0), src, tmp, nullptr);
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems, CV.obase};
+                rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc;
                 if (hoh) {
                     SD.level = lv_final;
-                    k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(1), tmp, tmp2, nullptr);
+                    rc = launch_spmm(h, SD, CV, P, 1, tmp, tmp2, grid_mf); if (rc) return rc;
                 }
                 G.in = hoh ? tmp2 : tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
                 if (!hoh) {
@@ -892,7 +1017,7 @@ extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_
         HIPCK(h, hipMemcpyAsync(h->d_seed.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         ChainView CV;
-        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
+        CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
         for (int v = 0; v < 2; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nc * velems * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(ca, 0, (size_t)nch * 2 * lld * sizeof(double), h->stream));
         k_scalar_seed<<<nc, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), cb, lld);

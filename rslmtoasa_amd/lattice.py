@@ -40,6 +40,14 @@ def bcc_supercell(dims, slot_vec, primitive=BCC_PRIMITIVE):
     return nn
 
 
+def supercell_positions(dims, primitive=BCC_PRIMITIVE):
+    """Cartesian positions (3, kk) of the supercell atoms in units of alat, same atom numbering as bcc_supercell."""
+    n1, n2, n3 = (int(x) for x in dims)
+    c1, c2, c3 = np.meshgrid(np.arange(n1), np.arange(n2), np.arange(n3), indexing="ij")
+    cells = np.stack([c.ravel(order="F") for c in (c1, c2, c3)], axis=1).astype(np.float64)
+    return np.asfortranarray((cells @ primitive).T)
+
+
 def spread_sites(kk, nsites):
     """Seed sites 1 + k*floor(kk/S), k = 0..S-1, 1-based like ``irec``."""
     stride = max(kk // max(nsites, 1), 1)

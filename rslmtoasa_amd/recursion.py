@@ -43,6 +43,7 @@ class Lattice:
     nmax: int = 0
     ntype: int = 1
     ijpair: np.ndarray = None  # (njij, 2) atom pairs for recur_b_ij (lattice%ijpair)
+    cr: np.ndarray = None      # (3, kk) positions, lattice%cr -- optional locality hint for the engine
 
     @property
     def kk(self):
@@ -125,6 +126,7 @@ class Recursion:
     def set_option(self, key, value):
         self._check(self._L.rsrec_set_option(self._h, key.encode(), int(value)))
 
+
     def timing(self):
         out = (C.c_double * 8)()
         self._L.rsrec_get_timing(self._h, out, 8)
@@ -150,6 +152,10 @@ class Recursion:
         self._nn = _fc(lat.nn, np.int32)
         self._iz = _fc(lat.iz, np.int32)
         self._check(self._L.rsrec_set_lattice(self._h, lat.kk, self._nn.shape[1], _ptr(self._nn), _ptr(self._iz), int(lat.nmax), int(lat.ntype)))
+        if lat.cr is not None:
+            cr = _fc(lat.cr, np.float64)
+            assert cr.shape == (3, lat.kk)
+            self._check(self._L.rsrec_set_positions(self._h, _ptr(cr)))
 
     def update_hamiltonian(self):
         """Must be called whenever the caller rebuilt the blocks (self.f90:777-797 does before every recur*)."""

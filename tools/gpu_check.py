@@ -30,6 +30,8 @@ def block(name, kernels):
     ham, lat, ctl, en = objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
     rec = Recursion(ham, lat, ctl, en)
     rec.set_option("kernels", kernels)
+    if os.environ.get("RSREC_SPMM4"):
+        rec.set_option("spmm4", int(os.environ["RSREC_SPMM4"]))
     rec.recur_b()
     n = g["nrec"]
     tm = rec.timing()
@@ -69,6 +71,8 @@ def supercell(name, kernels, nsites=1):
     rec.set_option("kernels", kernels)
     if os.environ.get("RSREC_WPS"):
         rec.set_option("wps", int(os.environ["RSREC_WPS"]))
+    if os.environ.get("RSREC_SPMM4"):
+        rec.set_option("spmm4", int(os.environ["RSREC_SPMM4"]))
     if int(g["kind"]) == 0:
         rec.recur_b()
         n = len(g["irec"])
