@@ -34,7 +34,10 @@ from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recur
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); rate measured here: profiles/ubench_f64_r01.txt
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
-HOP_TRAFFIC_BYTES_PER_LAUNCH = None   # HBM bytes per H|psi> launch from rocprofv3 PMC passes (profiles/); None until measured
+# Memory-side bytes per H|psi> launch of the DEFAULT workload (22^3 atoms, 64 sites, LL=50), from separate rocprofv3 --pmc passes
+# (profiles/r01_spmm4_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 35.96 GB + 3.80 GB.
+# The counters sit on the L2's fabric side, so Infinity-Cache hits of the neighbour gathers are included.
+HOP_TRAFFIC_BYTES_PER_LAUNCH = 39.75e9
 BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
 
 
@@ -165,6 +168,8 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
+        default_workload = (args.cells == 22 and args.sites == 64 and args.lld == 50 and not args.kernels and not args.batch
+                            and args.spmm4 < 0 and not args.no_positions)
         # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + 5.0 * tm_acc["atom_steps"])
         flop_total = flop_rank * world
@@ -195,7 +200,7 @@ def main():
             "device_ms_per_step": tm_acc["total_ms"] / args.steps,
             "host_ms_per_step": tm_acc["host_ms"] / args.steps,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH, "kernel": "k_mfma_spmm (H|psi> block SpMM)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
+                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None, "kernel": "k_spmm4 (H|psi> block SpMM, FP64 MFMA 4x4x4)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
                          "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
                                       "note": "whole recursion level, algorithmic 51840 B per atom-step"}},

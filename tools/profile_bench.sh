@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence bench.py's roofline object cites: a kernel-trace/stats pass and separate PMC passes
+# (FETCH_SIZE, WRITE_SIZE, TCC hit/miss -- one counter set per pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Usage (on the GPU box): tools/profile_bench.sh <tag>   -> gpurun_out/prof_<tag>/{stats,pmc_*}, gpurun_out/prof_<tag>/summary.txt
+set -e
+TAG=${1:-run}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 1 --warmup 0 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.log
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $C | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_$N.log
+done
+python3 $ROOT/tools/summarize_pmc.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt
