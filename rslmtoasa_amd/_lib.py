@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsrec.so")
+# RSREC_LIB: development override (kernel timing probes build variant libraries); there is still no fallback
+LIB_PATH = os.environ.get("RSREC_LIB") or os.path.join(_HERE, "librsrec.so")
 
 ERR_ARG, ERR_DEVICE, ERR_DIVERGED, ERR_EIG = 1, 2, 3, 4
 

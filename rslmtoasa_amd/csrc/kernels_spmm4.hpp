@@ -22,6 +22,9 @@
 
 namespace rsrec {
 
+#ifndef S4_PROBE
+#define S4_PROBE 0   // timing probes only (tools/probe_spmm_bound.sh): 1 = no operator-fragment loads, 2 = no psi loads in the k-loop
+#endif
 constexpr int S4_FRAG_PER_SLOT = 9 * 9 * 64;   // doubles: [q][rb][lane]
 constexpr int S4_MAXSLOTS = 32;
 
@@ -137,60 +140,105 @@ __device__ __forceinline__ void s4_mfma_step(double (&acc)[9][9], const double (
     }
 }
 
+// number of structurally non-zero row blocks of k-step q
+__host__ __device__ constexpr int s4_nrb(int pat, int q) {
+    int n = 0;
+    for (int rb = 0; rb < 9; ++rb) n += s4_nz(pat, rb, q) ? 1 : 0;
+    return n;
+}
+// Issue order of one k-step: every operand load (with the one VALU add that forms its 32-bit offset) is followed by PER MFMAs.
+// At one wave per SIMD nothing else covers a load's issue slot: left to itself hipcc puts the ~18 loads of a k-step in
+// one burst, during which the matrix pipe drains and idles (measured: 46 % of the kernel, tools/probe_spmm_bound.sh).
+template <int NA, int NM>
+__device__ __forceinline__ void s4_interleave() {
+    constexpr int PER = NM / (9 + NA);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {                            // psi operands: one offset add + one load each
+        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);     // VALU
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);    // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x8, PER, 0);   // MFMA
+    }
+    __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);         // operator fragments: one 64-bit base for the k-step, immediate offsets
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, PER, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, NM - PER * (9 + NA), 0);
+}
+
 // All slots of one pattern for one wave: operand ring (3 buffers, loads two k-steps ahead) + MFMAs.
 // (A variant that keeps the ring alive across passes and groups was measured: hipcc then spills ~23 doubles per lane and
 //  the kernel gets 6-13 % slower, so every pass primes its own ring.)
 template <int PAT>
 __device__ __forceinline__ void s4_run_slots(double (&acc)[9][9], const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ in,
-                                             const int* __restrict__ nbr, const int (&atom)[GROUP], int my_rem_atom, int nslots, int zero_block, int l15,
-                                             const int (&koff)[9]) {
+                                             const int* __restrict__ nbr, const int (&atom)[GROUP], int nslots, int zero_block, int l15,
+                                             const unsigned (&koff)[9] /*bytes*/, unsigned lane8) {
     const int nmine = share[0];
     if (nmine <= 0) return;
-    auto load_src = [&](int s, unsigned (&src)[9]) {
+    const char* __restrict__ inb = reinterpret_cast<const char*>(in);
+    // Neighbour indices are wave-uniform (scalar loads).  They are fetched one whole slot ahead and only turned into
+    // lane addresses right before the k-step that first needs them, so the index latency hides behind ~440 MFMAs
+    // (waiting on them at the top of the slot cost a full memory round trip per slot at one wave per SIMD).
+    auto load_idx = [&](int s, int (&n)[GROUP]) {
+#pragma unroll
+        for (int t = 0; t < GROUP; ++t) n[t] = nbr[(size_t)nslots * max(atom[t], 0) + s];
+    };
+    const int rem_t = l15 >> 1;            // atom of this lane's remainder-tile column
+    auto make_src = [&](const int (&n)[GROUP], unsigned (&src)[9]) {
+        int mr = zero_block;
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) {
-            int n = atom[t] >= 0 ? nbr[(size_t)nslots * atom[t] + s] : -1;
-            if (n < 0) n = zero_block;
-            src[t] = (unsigned)BLD * n + l15;
+            const int m = (atom[t] >= 0 && n[t] >= 0) ? n[t] : zero_block;
+            src[t] = ((unsigned)BLD * m + l15) * 8u;          // byte offsets: 32-bit, added to the wave-uniform base by the load itself
+            mr = (rem_t == t) ? m : mr;
         }
-        int n = my_rem_atom >= 0 ? nbr[(size_t)nslots * my_rem_atom + s] : -1;
-        if (n < 0) n = zero_block;
-        src[8] = (unsigned)BLD * n + 16 + (l15 & 1);
+        src[8] = ((unsigned)BLD * mr + 16 + (l15 & 1)) * 8u;
     };
     unsigned src[9], srcn[9];
+    int nraw[GROUP];
     double bq[3][9], aq[3][9];
     int s_cur = share[1];
-    load_src(s_cur, src);
+    int s_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
+    load_idx(s_cur, nraw);
+    make_src(nraw, src);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) bq[p][t] = in[src[t] + koff[p]];
+        for (int t = 0; t < 9; ++t) bq[p][t] = *reinterpret_cast<const double*>(inb + (src[t] + koff[p]));
 #pragma unroll
         for (int rb = 0; rb < 9; ++rb)
-            if (s4_nz(PAT, rb, p)) aq[p][rb] = fr[(size_t)s_cur * S4_FRAG_PER_SLOT + (p * 9 + rb) * 64];
+            if (s4_nz(PAT, rb, p))
+                aq[p][rb] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(fr + (size_t)s_cur * S4_FRAG_PER_SLOT + (p * 9 + rb) * 64) + lane8);
     }
     for (int j = 0; j < nmine; ++j) {
-        const int s_nxt = share[1 + ((j + 1 < nmine) ? j + 1 : 0)];   // the last slot prefetches the first again (discarded)
-        load_src(s_nxt, srcn);
+        // the last slot prefetches the first again (discarded)
+        const int s_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];
+        load_idx(s_nxt, nraw);
         const double* __restrict__ fs = fr + (size_t)s_cur * S4_FRAG_PER_SLOT;
         const double* __restrict__ fsn = fr + (size_t)s_nxt * S4_FRAG_PER_SLOT;
 #define S4_KSTEP(Q)                                                                                                    \
     {                                                                                                                  \
         constexpr int cur = (Q) % 3, nxt = ((Q) + 2) % 3, qn = ((Q) + 2) % 9;                                          \
-        /* fragment base of k-step qn, centred on row block 4 so that every load has a small immediate offset */       \
-        const double* __restrict__ fa = (((Q) + 2 < 9) ? fs : fsn) + (qn * 9 + 4) * 64;                                \
+        /* fragment base of k-step qn (wave-uniform), centred on row block 4: every load = SGPR base + lane offset + immediate */ \
+        const char* __restrict__ fa = reinterpret_cast<const char*>((((Q) + 2 < 9) ? fs : fsn) + (qn * 9 + 4) * 64);   \
         const unsigned* sp = ((Q) + 2 < 9) ? src : srcn;                                                               \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) bq[nxt][t] = in[sp[t] + koff[qn]];                               \
-        _Pragma("unroll") for (int rb = 0; rb < 9; ++rb)                                                               \
-            if (s4_nz(PAT, rb, qn)) aq[nxt][rb] = fa[(rb - 4) * 64];                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (!(S4_PROBE & 2)) { _Pragma("unroll") for (int t = 0; t < 9; ++t)                                           \
+            bq[nxt][t] = *reinterpret_cast<const double*>(inb + (sp[t] + koff[qn])); }                                 \
+        if (!(S4_PROBE & 1)) { _Pragma("unroll") for (int rb = 0; rb < 9; ++rb)                                        \
+            if (s4_nz(PAT, rb, qn)) aq[nxt][rb] = reinterpret_cast<const double*>(fa + lane8)[(rb - 4) * 64]; }        \
         s4_mfma_step<PAT, Q>(acc, aq[cur], bq[cur]);                                                                   \
+        s4_interleave<s4_nrb(PAT, qn), 9 * s4_nrb(PAT, Q)>();                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
-        S4_KSTEP(0) S4_KSTEP(1) S4_KSTEP(2) S4_KSTEP(3) S4_KSTEP(4) S4_KSTEP(5) S4_KSTEP(6) S4_KSTEP(7) S4_KSTEP(8)
+        S4_KSTEP(0) S4_KSTEP(1) S4_KSTEP(2) S4_KSTEP(3) S4_KSTEP(4) S4_KSTEP(5) S4_KSTEP(6)
+        make_src(nraw, srcn);
+        S4_KSTEP(7) S4_KSTEP(8)
 #undef S4_KSTEP
 #pragma unroll
         for (int t = 0; t < 9; ++t) src[t] = srcn[t];
         s_cur = s_nxt;
+        s_nxt = s_nxt2;
     }
 }
 
@@ -213,9 +261,10 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_spmm4(SpmmDims D, const in
     double* __restrict__ out = out_all + vo;
     const int zero_block = D.kk;
     const int l15 = lane & 15, l4 = lane >> 4;
-    int koff[9];                       // this lane's k-row (4q + l4) of every k-step, as an element offset
+    unsigned koff[9];                  // this lane's k-row (4q + l4) of every k-step, as a byte offset
 #pragma unroll
-    for (int q = 0; q < 9; ++q) koff[q] = s4_row_offset(4 * q + l4);
+    for (int q = 0; q < 9; ++q) koff[q] = 8u * (unsigned)s4_row_offset(4 * q + l4);
+    const unsigned lane8 = 8u * (unsigned)lane;
 
     // group walk: with NSPLIT = 4 the WORKGROUP is the unit (same XCD-chunked sliding window as GroupWalk)
     int g, gend, gstep;
@@ -244,7 +293,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_spmm4(SpmmDims D, const in
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
         const int my_rem_atom = grp[l15 >> 1];
         const int* __restrict__ M = meta + (size_t)tau * Spmm4Operator::META + ((NSPLIT == 4) ? 1 + wave : 0) * 2 * (1 + S4_MAXSLOTS);
-        const double* __restrict__ fr = frag + (size_t)tau * D.nslots * S4_FRAG_PER_SLOT + lane;
+        const double* __restrict__ fr = frag + (size_t)tau * D.nslots * S4_FRAG_PER_SLOT;   // wave-uniform
 
         double acc[9][9];
 #pragma unroll
@@ -253,8 +302,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_spmm4(SpmmDims D, const in
             for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
 
         // one pass per structural pattern (each pass is a single straight-line body: mixing both in one loop made hipcc spill)
-        s4_run_slots<0>(acc, M, fr, in, nbr, atom, my_rem_atom, D.nslots, zero_block, l15, koff);
-        s4_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, in, nbr, atom, my_rem_atom, D.nslots, zero_block, l15, koff);
+        s4_run_slots<0>(acc, M, fr, in, nbr, atom, D.nslots, zero_block, l15, koff, lane8);
+        s4_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, in, nbr, atom, D.nslots, zero_block, l15, koff, lane8);
 
         // output rows of row block rb: ks = 4 rb + l4, column l15 (D layout of the 4x4x4 MFMA with blocks over N)
         int ro[9];
