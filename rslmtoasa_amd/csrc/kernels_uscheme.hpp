@@ -1,0 +1,206 @@
+// Block Lanczos on UN-NORMALISED vectors ("u-scheme"): the post-hop pipeline with one kernel fewer.
+//
+// The reference (crecal_b, recursion.f90:1873-1973) keeps psi_n orthonormal: psi_{n+1} = pmn B_{n+1}^-1 is formed and
+// stored at every level (:1963-1969).  Every operator on the path acts from the LEFT on the 18x18 blocks and every
+// coefficient matrix from the RIGHT, so the normalisation commutes with H and can be carried as a small matrix instead
+// of a pass over the vector:
+//     u_n := pmn of level n-1  (psi_n = u_n Binv_n,  B_n^2 = sum u_n^H u_n,  u_1 = seed, Binv_1 = I)
+//     t'   = H u_n                                                  (block SpMM, unchanged)
+//     A_n  = psi_n^H H psi_n = Binv_n (sum u_n^H t') Binv_n           (k_mfma_adot + k_reduce_a_u)
+//     u_{n+1} = H psi_n - psi_n A_n - psi_{n-1} B_n
+//             = t' Binv_n  -  u_n (Binv_n A_n)  -  u_{n-1} (Binv_{n-1} B_n)     (k_mfma_orth3, three 36x36 right-multiplies)
+//     B_{n+1}^2 = sum u_{n+1}^H u_{n+1}  -> eigen-decomposition -> B_{n+1}, Binv_{n+1}   (k_reduce_b_u)
+// Per atom-step this reads t', u_n, u_{n-1} and writes u_{n+1} in place of u_{n-1}: 3 block reads + 1 write after the
+// SpMM (+2 reads for A_n), against 4 reads + 2 writes (+2) for the normalised three-term form.  The coefficients A_n,
+// B_n^2 are the same matrices up to rounding (checked against the reference's golden coefficients, tests/test_gpu_parity.py).
+//
+// Operand loads are 16 bytes per lane: the A-operand lane (row l15, k = l4) of MFMA k-step q < 8 takes column
+// 8 (q >> 1) + 2 l4 + (q & 1), so two consecutive k-steps come from one double2; the fragment tables use the same k order.
+#pragma once
+#include "kernels_mfma.hpp"
+
+namespace rsrec {
+
+__host__ __device__ constexpr int pk_col(int q, int l4) { return q < 8 ? 8 * (q >> 1) + 2 * l4 + (q & 1) : 32 + l4; }
+
+// fragment table of G (18x18 complex, column-major) for [X_re | X_im] * Ghat with the paired k order
+__device__ __forceinline__ void emit_rhs_frags_pk(const double2* M, double sign, double* out) {
+    for (int e = threadIdx.x; e < 27 * 64; e += blockDim.x) {
+        const int l = e & 63, qf = e >> 6, q = qf / 3, f = qf % 3;
+        const int ki = pk_col(q, l >> 4);
+        const int ko = (f < 2) ? 16 * f + (l & 15) : 32 + (l & 3);
+        const int pi = ki / 18, ci = ki % 18, po = ko / 18, co = ko % 18;
+        const double2 g = M[ci + 18 * co];
+        const double v = (pi == po) ? g.x : (pi == 0 ? g.y : -g.y);
+        out[e] = sign * v;
+    }
+}
+
+// C = A * B for 18x18 complex column-major matrices in LDS (all threads of the block; caller syncs)
+__device__ __forceinline__ void matmul18(const double2* A, const double2* B, double2* C) {
+    for (int e = threadIdx.x; e < BLK; e += blockDim.x) {
+        const int i = e % NB, j = e / NB;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int k = 0; k < NB; ++k) {
+            const double2 a = A[i + NB * k], b = B[k + NB * j];
+            acc.x += a.x * b.x - a.y * b.y;
+            acc.y += a.x * b.y + a.y * b.x;
+        }
+        C[e] = acc;
+    }
+}
+
+struct U3Operands { double2 x[4]; double y; };
+
+__device__ __forceinline__ void u3_load(U3Operands& o, const double* __restrict__ base, unsigned off, int l4) {
+    const double2* p = reinterpret_cast<const double2*>(base + off + 2 * l4);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) o.x[qq] = p[4 * qq];        // columns 8 qq + 2 l4, +1
+    o.y = base[off + 32 + l4];
+}
+
+template <int Q>
+__device__ __forceinline__ double u3_k(const U3Operands& o) { return Q < 8 ? ((Q & 1) ? o.x[Q >> 1].y : o.x[Q >> 1].x) : o.y; }
+
+__device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr, const U3Operands& o, const double (&T)[27]) {
+#define U3_STEP(Q)                                                                              \
+    {                                                                                           \
+        const double a = u3_k<Q>(o);                                                            \
+        ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[3 * (Q) + 0], ca, 0, 0, 0);              \
+        cb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[3 * (Q) + 1], cb, 0, 0, 0);              \
+        cr = __builtin_amdgcn_mfma_f64_4x4x4f64(a, T[3 * (Q) + 2], cr, 0, 0, 0);                \
+    }
+    U3_STEP(0) U3_STEP(1) U3_STEP(2) U3_STEP(3) U3_STEP(4) U3_STEP(5) U3_STEP(6) U3_STEP(7) U3_STEP(8)
+#undef U3_STEP
+}
+
+// u_next = t' T1 + u_prev T2 + u_cur T3, written over u_prev; Gram partial of u_next.
+// tabs[chain][3][27*64]: T1 = Binv_n, T2 = -Binv_{n-1} B_n, T3 = -Binv_n A_n (paired-k fragment tables).
+// One wave per SIMD (the three tables live in registers); the next row tile's operands are fetched before the current
+// tile's MFMAs so each wave keeps ~14 KB of reads in flight.
+__global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
+                                                                const double* __restrict__ ucur, double* uprev,
+                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/) {
+    __shared__ double lds[MF_WAVES * 1296];
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain, level);
+    const size_t vo = (size_t)chain * CV.vstride;
+    const double* tv = tvec + vo;
+    const double* uc = ucur + vo;
+    double* up = uprev + vo;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+    double T1[27], T2[27], T3[27];
+    {
+        const double* f = tabs + (size_t)chain * 3 * 27 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 27; ++e) { T1[e] = f[e * 64]; T2[e] = f[(27 + e) * 64]; T3[e] = f[(54 + e) * 64]; }
+    }
+    GramAcc Gm;
+    Gm.zero();
+    GroupWalk w(ngroups, wave);
+    U3Operands ot, oc, op;
+    if (w.g < w.end) {
+        const RowRef ra = group_row(order + (size_t)w.g * GROUP, l15, zero_block);
+        u3_load(ot, tv, ra.off, l4); u3_load(oc, uc, ra.off, l4); u3_load(op, up, ra.off, l4);
+    }
+    for (; w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
+#pragma unroll 1
+        for (int mt = 0; mt < 9; ++mt) {
+            // operands of the next row tile (next group after the last tile; re-reads the current tile at the very end)
+            U3Operands nt, nc, np;
+            {
+                const bool last = (mt == 8);
+                const int gn = last ? ((w.g + w.step < w.end) ? w.g + w.step : w.g) : w.g;
+                const RowRef rn = group_row(order + (size_t)gn * GROUP, last ? l15 : 16 * (mt + 1) + l15, zero_block);
+                u3_load(nt, tv, rn.off, l4); u3_load(nc, uc, rn.off, l4); u3_load(np, up, rn.off, l4);
+            }
+            double4_t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+            double cr = 0.0;
+            u3_mac(ca, cb, cr, ot, T1);
+            u3_mac(ca, cb, cr, op, T2);
+            u3_mac(ca, cb, cr, oc, T3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
+                if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
+            }
+            const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
+            if (rr.valid) up[rr.off + 32 + l3] = cr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double f0 = ca[j], f1 = cb[j];
+                const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);
+                Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
+                Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
+                Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
+                Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
+                Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
+                Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
+            }
+            ot = nt; oc = nc; op = np;
+        }
+    }
+    gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
+}
+
+// G = sum u_n^H t'  ->  A_n = Binv_n G Binv_n (the coefficient, recursion.f90:1642), T3 = -Binv_n A_n
+__global__ __launch_bounds__(1024) void k_reduce_a_u(const double* __restrict__ partial, int nblk, double2* a_out, size_t astride,
+                                                    const double2* __restrict__ Bmats /*[chain][2][324]: B_n, Binv_n*/, double* tabs) {
+    __shared__ double lds[1296];
+    __shared__ double2 Gm[BLK], Bi[BLK], M1[BLK], M2[BLK];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    if (threadIdx.x < BLK) { Gm[threadIdx.x] = c; Bi[threadIdx.x] = Bmats[(size_t)chain * 2 * BLK + BLK + threadIdx.x]; }
+    __syncthreads();
+    matmul18(Gm, Bi, M1);            // G Binv
+    __syncthreads();
+    matmul18(Bi, M1, M2);            // A = Binv G Binv
+    __syncthreads();
+    if (threadIdx.x < BLK) a_out[chain * astride + threadIdx.x] = M2[threadIdx.x];
+    matmul18(Bi, M2, M1);            // Binv A
+    __syncthreads();
+    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 2) * 27 * 64);
+}
+
+// B_{n+1}^2 = sum u_{n+1}^H u_{n+1} (b2_b, recursion.f90:1931) -> B_{n+1}, Binv_{n+1} (:1937-1960);
+// tables for the next level: T1 = Binv_{n+1}, T2 = -Binv_n B_{n+1}
+__global__ __launch_bounds__(1024) void k_reduce_b_u(const double* __restrict__ partial, int nblk, double2* b2_out, size_t bstride, double2* Bmats,
+                                                    double* tabs, int* status) {
+    __shared__ double lds[1296];
+    __shared__ Eig18Shared sh;
+    __shared__ double2 Bn[BLK], Bin[BLK], Bold[BLK], M1[BLK];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    double2* Bout = Bmats + (size_t)chain * 2 * BLK;
+    if (threadIdx.x < BLK) { b2_out[chain * bstride + threadIdx.x] = c; sh.A[threadIdx.x] = c; Bold[threadIdx.x] = Bout[BLK + threadIdx.x]; }
+    __syncthreads();
+    const int sw = jacobi18(sh);
+    if (sw < 0 && threadIdx.x == 0) atomicOr(status, 1);
+    if (threadIdx.x < NB) { const double l = sqrt(sh.ev[threadIdx.x]); sh.f1[threadIdx.x] = l; sh.f2[threadIdx.x] = 1.0 / l; }
+    __syncthreads();
+    matfun18(sh, sh.f1, Bn);
+    matfun18(sh, sh.f2, Bin);
+    __syncthreads();
+    matmul18(Bold, Bn, M1);          // Binv_n B_{n+1}
+    for (int e = threadIdx.x; e < BLK; e += blockDim.x) { Bout[e] = Bn[e]; Bout[BLK + e] = Bin[e]; }
+    __syncthreads();
+    emit_rhs_frags_pk(Bin, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64);
+    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 1) * 27 * 64);
+}
+
+// initial state of a chain: B_1 = Binv_1 = I, T1 = I, T2 = T3 = 0
+__global__ void k_uscheme_init(double2* Bmats, double* tabs) {
+    __shared__ double2 I[BLK];
+    const int chain = blockIdx.x;
+    for (int e = threadIdx.x; e < BLK; e += blockDim.x) I[e] = make_double2((e % NB) == (e / NB) ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * BLK; e += blockDim.x) Bmats[(size_t)chain * 2 * BLK + e] = I[e % BLK];
+    emit_rhs_frags_pk(I, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64);
+    for (int e = threadIdx.x; e < 2 * 27 * 64; e += blockDim.x) tabs[((size_t)chain * 3 + 1) * 27 * 64 + e] = 0.0;
+}
+
+}  // namespace rsrec

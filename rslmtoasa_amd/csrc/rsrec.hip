@@ -25,6 +25,7 @@
 #include "kernels_valu.hpp"
 #include "kernels_mfma.hpp"
 #include "kernels_spmm4.hpp"
+#include "kernels_uscheme.hpp"
 
 using namespace rsrec;
 
@@ -66,7 +67,7 @@ struct rsrec_handle {
     // work
     DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 1, opt_spmm4 = -1, opt_fuse = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -612,6 +613,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
     const int nvec = MFMA ? 4 : (hoh ? 3 : 2);
     const bool three_term = MFMA && !hoh && h->opt_post != 1 && !h->opt_fuse && h->opt_three;
+    const bool u_scheme = three_term && h->opt_three == 2 && h->opt_wps != 2;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -672,6 +674,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (the three-term scheme swaps them every level)
         k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
+        if (u_scheme) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
@@ -705,6 +708,17 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     tvec = hpsi;
                     if (mf_post) {
                         k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                        if (u_scheme) {
+                            // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
+                            k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                            k_mfma_orth3<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                            k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                      h->d_status.as<int>());
+                            std::swap(psi, t2);
+                            hop_ev.emplace_back(e0, e1);
+                            h->n_hop_launch += 1;
+                            continue;
+                        }
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
                         if (three_term) {
                             // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
