@@ -1,0 +1,330 @@
+// Block-sparse H|psi>, third generation ("spmm5"): spin-split waves, 16-byte operand loads, two waves per SIMD.
+//
+// What the profiles of the previous kernel (k_spmm4, profiles/r01_spmm4_rocprof_summary.txt + tools/pmc_sq.sh) showed:
+// the matrix pipe was busy 51 % of the time, the waves spent 65 % of their cycles stalled at instruction issue, and removing
+// the operand LOADS from the k-loop (results wrong, timing only: tools/probe_spmm_bound.sh) made the kernel 1.8x faster no
+// matter where the data came from.  With one 500-register wave per SIMD every 8-byte-per-lane global load costs the wave
+// ~45 cycles of issue that nothing else covers, and 130 of them per neighbour slot also keep the CU's address unit busy
+// ~2100 of the slot's 7056 matrix cycles.  This kernel attacks the load count and the exposure:
+//   * rows of the real form are ordered spin-major and each spin padded from 18 to 20 rows (5 four-row blocks): the
+//     collinear operators (no spin-flip hopping; hamiltonian.f90:1553-1617) are then exactly block diagonal at MFMA
+//     granularity and ONE WAVE OWNS ONE SPIN of a group of 8 atoms: 45 accumulators instead of 162, so two waves fit
+//     on a SIMD and cover each other's issue stalls.  Spin-mixing blocks (spin-orbit on-site term, non-collinear
+//     operators) take the same path with both input spins.
+//   * the input vector is read in the k-pair ("KP") layout written by the producing kernel (k_mfma_orth3, k_rm_to_kp):
+//     the B operands of two consecutive k-steps are adjacent, so one 16-byte load feeds two MFMA k-steps; the operator
+//     fragments are stored the same way.  Per slot and wave: 42 loads for 225 MFMAs (before: 130 for 441).
+//   * neighbour blocks are wave-uniform: their addresses are SGPR bases, the lane part of every address is one of three
+//     loop-invariant registers, everything else an instruction immediate: no address arithmetic on the vector ALU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+#include "kernels_valu.hpp"
+#include "kernels_mfma.hpp"
+#include "kernels_spmm4.hpp"
+
+namespace rsrec {
+
+// element (orbital row r, re/im part, column c) of an 18x18 complex block in the KP layout (648 doubles, a bijection):
+// per spin sigma = r / 9 a 324-double half; real-form row w = 9 part + m (m = r % 9), k-pair p = w >> 3, lane row l4 = w & 3,
+// pair member e = (w >> 2) & 1; rows 16, 17 form the spin's fifth (half-empty) k-step.
+__host__ __device__ constexpr int kp_offset(int r, int part, int c) {
+    const int sigma = r / 9, m = r % 9, w = 9 * part + m, base = 324 * sigma;
+    if (c < 16) return w < 16 ? base + 128 * (w >> 3) + 32 * (w & 3) + 2 * c + ((w >> 2) & 1) : base + 256 + 16 * (w - 16) + c;
+    const int cc = c - 16;
+    return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
+}
+
+constexpr int S5_FRAG_PER_RB = 320;                         // doubles: pair 0 (128), pair 1 (128), single (64)
+constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][sigma_in][rb]
+
+struct Spmm5Operator {
+    double* d_frag = nullptr;    // [set][tau][slot][sigma_out][sigma_in][rb][320]
+    int* d_meta = nullptr;       // [set][tau][pattern][1 + S4_MAXSLOTS]: slot lists (0 = spin-mixing, 1 = spin-diagonal)
+    size_t frag_bytes = 0, meta_bytes = 0;
+    int ntau = 0, nslots = 0, have_o = 0;
+    static constexpr int META = 2 * (1 + S4_MAXSLOTS);
+
+    void release() {
+        if (d_frag) (void)hipFree(d_frag);
+        if (d_meta) (void)hipFree(d_meta);
+        d_frag = nullptr; d_meta = nullptr; frag_bytes = meta_bytes = 0;
+    }
+    // entry (row ko, column ki) of the padded 40x40 real form: index = 20 sigma + w, w = 9 part + m, w = 18, 19 are padding
+    static double real40(const double* blk, int ko, int ki) {
+        const int so = ko / 20, wo = ko % 20, si = ki / 20, wi = ki % 20;
+        if (wo >= 18 || wi >= 18) return 0.0;
+        const int po = wo / 9, mo = wo % 9, pi = wi / 9, mi = wi % 9;
+        const int ro = 9 * so + mo, ri = 9 * si + mi;
+        const double hr = blk[2 * (ro + 18 * ri)], hi = blk[2 * (ro + 18 * ri) + 1];
+        if (po == pi) return hr;
+        return po == 0 ? -hi : hi;
+    }
+    static void swizzle(const double* blk, double* out) {
+        for (int so = 0; so < 2; ++so)
+            for (int si = 0; si < 2; ++si)
+                for (int rb = 0; rb < 5; ++rb) {
+                    double* o = out + ((so * 2 + si) * 5 + rb) * S5_FRAG_PER_RB;
+                    for (int l = 0; l < 64; ++l) {       // A operand of the 4x4x4 MFMA: lane (i + 4 g + 16 k) = A[i][k], same for the 4 blocks g
+                        const int ko = 20 * so + 4 * rb + (l & 3), k = l >> 4;
+                        for (int p = 0; p < 2; ++p)
+                            for (int e = 0; e < 2; ++e) o[128 * p + 2 * l + e] = real40(blk, ko, 20 * si + 8 * p + 4 * e + k);
+                        o[256 + l] = real40(blk, ko, 20 * si + 16 + k);
+                    }
+                }
+    }
+    const char* build(int nslots_lat, int hstride, int ntype, int nmax, int hoh, const double* st, const double* loc, const double* eeo, const double* hallo) {
+        if (nslots_lat > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
+        ntau = nmax + ntype; nslots = nslots_lat; have_o = hoh ? 1 : 0;
+        const int nset = have_o ? 2 : 1;
+        const size_t per_set = (size_t)ntau * nslots * S5_FRAG_PER_SLOT;
+        std::vector<double> host(per_set * nset, 0.0);
+        std::vector<int> meta((size_t)nset * ntau * META, 0);
+        for (int set = 0; set < nset; ++set)
+            for (int tau = 0; tau < ntau; ++tau) {
+                int* M = meta.data() + ((size_t)set * ntau + tau) * META;
+                for (int s = 0; s < nslots; ++s) {
+                    const double* src;
+                    if (tau < nmax) src = (set ? hallo : loc) + 2 * (size_t)BLK * (s + (size_t)hstride * tau);
+                    else src = (set ? eeo : st) + 2 * (size_t)BLK * (s + (size_t)hstride * (tau - nmax));
+                    swizzle(src, host.data() + set * per_set + ((size_t)tau * nslots + s) * S5_FRAG_PER_SLOT);
+                    int* W = M + Spmm4Operator::pattern_of(src) * (1 + S4_MAXSLOTS);
+                    W[1 + W[0]] = s; W[0]++;
+                }
+            }
+        const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
+        if (need > frag_bytes) {
+            if (d_frag) (void)hipFree(d_frag);
+            d_frag = nullptr; frag_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&d_frag), need) != hipSuccess) return "hipMalloc of spmm5 operator fragments failed";
+            frag_bytes = need;
+        }
+        if (mneed > meta_bytes) {
+            if (d_meta) (void)hipFree(d_meta);
+            d_meta = nullptr; meta_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&d_meta), mneed) != hipSuccess) return "hipMalloc of spmm5 schedule failed";
+            meta_bytes = mneed;
+        }
+        if (hipMemcpy(d_frag, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 fragments failed";
+        if (hipMemcpy(d_meta, meta.data(), mneed, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 schedule failed";
+        return nullptr;
+    }
+    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * nslots * S5_FRAG_PER_SLOT; }
+    const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
+};
+
+typedef double s5_d2 __attribute__((ext_vector_type(2)));
+struct S5Pair { s5_d2 b[9]; s5_d2 a[5]; };      // operands of two k-steps: psi tiles, operator row blocks
+struct S5Single { double b[9]; double a[5]; };  // the spin's fifth k-step (rows 16, 17 + padding)
+
+// wave-uniform addressing state of one neighbour slot
+struct S5Slot {
+    const char* tile[GROUP];   // KP block of the neighbour of atom t (spin 0 half)
+    unsigned rem;              // remainder tile: byte offset of this lane's neighbour block (per lane: atom l15 >> 1)
+};
+
+template <int P>
+__device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
+                                             unsigned lane_main, unsigned lane_rem, unsigned lane16) {
+#pragma unroll
+    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1024 * P);
+    o.b[8] = *reinterpret_cast<const s5_d2*>(inb + spin_off + (S.rem + lane_rem) + 128 * P);
+#pragma unroll
+    for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
+}
+__device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
+                                               unsigned lane_single, unsigned lane_rem_single, unsigned lane8) {
+#pragma unroll
+    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const double*>(S.tile[t] + spin_off + lane_single);
+    o.b[8] = *reinterpret_cast<const double*>(inb + spin_off + (S.rem + lane_rem_single));
+#pragma unroll
+    for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const double*>(fb + lane8 + (rb * S5_FRAG_PER_RB * 8 + 2048));
+}
+
+// issue order: one operand load, then PER MFMAs (see k_spmm4's s4_interleave)
+template <int NL, int NM>
+__device__ __forceinline__ void s5_interleave() {
+    constexpr int PER = NM / NL;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, PER, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, NM - PER * NL, 0);
+}
+
+__device__ __forceinline__ void s5_mfma_pair(double (&acc)[5][9], const S5Pair& o) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb][e], o.b[t][e], acc[rb][t], 0, 0, 0);
+}
+__device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Single& o) {
+#pragma unroll
+    for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb], o.b[t], acc[rb][t], 0, 0, 0);
+}
+
+// All slots of one pattern for one wave (output spin `sig`).  PAT = 1: the slot only couples equal spins (input spin = sig);
+// PAT = 0: both input spins.  Steps per (slot, input spin): pair 0, pair 1, single; the operands of the next step are loaded
+// while the MFMAs of the current one run.
+template <int PAT>
+__device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const char* __restrict__ inb,
+                                             const int* __restrict__ nbr, const int (&atom)[GROUP], int nslots, int zero_block, int sig, int l15,
+                                             unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
+    const int nmine = share[0];
+    if (nmine <= 0) return;
+    constexpr int NH = PAT == 0 ? 2 : 1;
+    auto load_idx = [&](int s, int (&n)[GROUP]) {
+#pragma unroll
+        for (int t = 0; t < GROUP; ++t) n[t] = nbr[(size_t)nslots * max(atom[t], 0) + s];
+    };
+    const int rem_t = l15 >> 1;
+    auto make_slot = [&](const int (&n)[GROUP], S5Slot& S) {
+        int mr = zero_block;
+#pragma unroll
+        for (int t = 0; t < GROUP; ++t) {
+            const int m = (atom[t] >= 0 && n[t] >= 0) ? n[t] : zero_block;
+            S.tile[t] = inb + (size_t)m * (BLD * 8);
+            mr = (rem_t == t) ? m : mr;
+        }
+        S.rem = (unsigned)mr * (BLD * 8u);
+    };
+    auto frag_of = [&](int s, int si) { return reinterpret_cast<const char*>(fr + ((size_t)s * 4 + (sig * 2 + si)) * (5 * S5_FRAG_PER_RB)); };
+    S5Slot cur, nxt;
+    int nraw[GROUP];
+    int s_cur = share[1];
+    int s_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
+    load_idx(s_cur, nraw);
+    make_slot(nraw, cur);
+    S5Pair X, Y;
+    S5Single Z;
+    const int si0 = PAT == 0 ? 0 : sig;
+    s5_load_pair<0>(X, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    for (int j = 0; j < nmine; ++j) {
+        const int s_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last slot prefetches the first again (discarded)
+        load_idx(s_nxt, nraw);
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int si = PAT == 0 ? hh : sig;
+            const unsigned so = 2592u * si;
+            const char* __restrict__ fb = frag_of(s_cur, si);
+            s5_load_pair<1>(Y, cur, inb, so, fb, lane_main, lane_rem, lane16);
+            s5_mfma_pair(acc, X);
+            s5_interleave<14, 90>();
+            __builtin_amdgcn_sched_barrier(0);
+            s5_load_single(Z, cur, inb, so, fb, lane_single, lane_rem_single, lane8);
+            s5_mfma_pair(acc, Y);
+            s5_interleave<14, 90>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (hh == NH - 1) {
+                make_slot(nraw, nxt);
+                s5_load_pair<0>(X, nxt, inb, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
+            } else {
+                s5_load_pair<0>(X, cur, inb, 2592u, frag_of(s_cur, 1), lane_main, lane_rem, lane16);
+            }
+            s5_mfma_single(acc, Z);
+            s5_interleave<14, 45>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
+        s_cur = s_nxt;
+        s_nxt = s_nxt2;
+    }
+}
+
+// One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
+// different spin) land on the same SIMD.  in_kp: KP layout; out: LayoutRM (read by the Gram / orthogonalisation kernels).
+__global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
+                                               const int* __restrict__ nbr, const int* __restrict__ izp, const double* __restrict__ frag,
+                                               const int* __restrict__ meta, const double* __restrict__ in_all, double* __restrict__ out_all) {
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sig = wave >> 2, gslot = wave & 3;
+    const int count = cum[(chain / D.cpo) * D.nlev + D.level];
+    const int ngroups = count / GROUP;
+    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
+    const size_t vo = (size_t)chain * D.vstride;
+    const char* __restrict__ inb = reinterpret_cast<const char*>(in_all + vo);
+    double* __restrict__ out = out_all + vo;
+    const int zero_block = D.kk;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const unsigned lane_main = 8u * (32 * l4 + 2 * l15), lane_single = 8u * (256 + 16 * (l4 & 1) + l15);
+    const unsigned lane_rem = 8u * (288 + 4 * l4 + 2 * (l15 & 1)), lane_rem_single = 8u * (320 + 2 * (l4 & 1) + (l15 & 1));
+    const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
+
+    int g, gend, gstep;
+    {
+        const int nbx = gridDim.x, bx = blockIdx.x;
+        if (nbx < 8) { g = bx * 4 + gslot; gend = ngroups; gstep = nbx * 4; }
+        else {
+            const int xcd = bx & 7, j = bx >> 3;
+            const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
+            const int chunk = (ngroups + 7) >> 3;
+            const int lo = xcd * chunk;
+            gend = min(ngroups, lo + chunk);
+            g = lo + j * 4 + gslot;
+            gstep = per_xcd * 4;
+        }
+    }
+    for (; g < gend; g += gstep) {
+        const int* __restrict__ grp = order + (size_t)g * GROUP;
+        int atom[GROUP];
+#pragma unroll
+        for (int t = 0; t < GROUP; ++t) atom[t] = grp[t];
+        const int first = atom[0];
+        const int tau = first < D.nmax ? first : D.nmax + izp[first];
+        const int my_rem_atom = grp[l15 >> 1];
+        const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
+        const double* __restrict__ fr = frag + (size_t)tau * D.nslots * S5_FRAG_PER_SLOT;
+
+        double acc[5][9];
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
+
+        s5_run_slots<0>(acc, M, fr, inb, nbr, atom, D.nslots, zero_block, sig, l15, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, inb, nbr, atom, D.nslots, zero_block, sig, l15, lane_main, lane_single, lane_rem, lane_rem_single,
+                        lane16, lane8);
+
+        // D layout: row w = 4 rb + l4 of spin sig (w = 18, 19: padding, exact zeros, not stored), column l15
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) {
+            const int w = 4 * rb + l4;
+            if (w >= 18) continue;
+            const int ro = 36 * (9 * sig + (w % 9)) + 18 * (w / 9);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int a = (t < 8) ? atom[t] : my_rem_atom;
+                if (a < 0) continue;
+                out[(size_t)BLD * a + ro + ((t < 8) ? l15 : 16 + (l15 & 1))] = acc[rb][t];
+            }
+        }
+    }
+}
+
+// LayoutRM -> KP copy of the blocks of one region list (seed blocks; paths whose producer does not write KP itself)
+__global__ __launch_bounds__(256) void k_rm_to_kp(ChainView CV, int level, const double* __restrict__ src, double* __restrict__ dst) {
+    const int chain = blockIdx.y;
+    const int count = CV.count_of(chain, level);
+    const int* order = CV.order_of(chain, level);
+    const size_t vo = (size_t)chain * CV.vstride;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int a = order[i];
+        if (a < 0) continue;
+        const double* s = src + vo + (size_t)BLD * a;
+        double* d = dst + vo + (size_t)BLD * a;
+        for (int e = threadIdx.x; e < BLD; e += blockDim.x) {
+            const int r = e / 36, c36 = e % 36;
+            d[kp_offset(r, c36 / 18, c36 % 18)] = s[e];
+        }
+    }
+}
+
+}  // namespace rsrec

@@ -18,6 +18,7 @@
 // 8 (q >> 1) + 2 l4 + (q & 1), so two consecutive k-steps come from one double2; the fragment tables use the same k order.
 #pragma once
 #include "kernels_mfma.hpp"
+#include "kernels_spmm5.hpp"
 
 namespace rsrec {
 
@@ -78,10 +79,18 @@ __device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr,
 // tabs[chain][3][27*64]: T1 = Binv_n, T2 = -Binv_{n-1} B_n, T3 = -Binv_n A_n (paired-k fragment tables).
 // One wave per SIMD (the three tables live in registers); the next row tile's operands are fetched before the current
 // tile's MFMAs so each wave keeps ~14 KB of reads in flight.
+// KP = true: u_next is also written in the k-pair layout the next level's SpMM (k_spmm5) reads.
+template <bool KP>
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                 const double* __restrict__ ucur, double* uprev,
-                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/) {
+                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/,
+                                                                double* ukp_all = nullptr) {
     __shared__ double lds[MF_WAVES * 1296];
+    __shared__ unsigned short kpt[KP ? BLD : 1];          // LayoutRM element (36 r + c36) -> KP offset
+    if (KP) {
+        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
+        __syncthreads();
+    }
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     const double* tv = tvec + vo;
     const double* uc = ucur + vo;
     double* up = uprev + vo;
+    double* uk = KP ? ukp_all + vo : nullptr;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     double T1[27], T2[27], T3[27];
     {
@@ -126,10 +136,19 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
-                if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
+                if (rs.valid) {
+                    up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j];
+                    if (KP) {
+                        const unsigned blk = (rs.off / BLD) * BLD, e0 = rs.off - blk;      // block base, 36 r
+                        uk[blk + kpt[e0 + l15]] = ca[j]; uk[blk + kpt[e0 + 16 + l15]] = cb[j];
+                    }
+                }
             }
             const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
-            if (rr.valid) up[rr.off + 32 + l3] = cr;
+            if (rr.valid) {
+                up[rr.off + 32 + l3] = cr;
+                if (KP) { const unsigned blk = (rr.off / BLD) * BLD; uk[blk + kpt[rr.off - blk + 32 + l3]] = cr; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double f0 = ca[j], f1 = cb[j];

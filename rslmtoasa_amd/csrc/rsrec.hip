@@ -25,6 +25,7 @@
 #include "kernels_valu.hpp"
 #include "kernels_mfma.hpp"
 #include "kernels_spmm4.hpp"
+#include "kernels_spmm5.hpp"
 #include "kernels_uscheme.hpp"
 
 using namespace rsrec;
@@ -64,10 +65,12 @@ struct rsrec_handle {
     MfmaOperator mfma_op;
     Spmm4Operator s4_op;
     int s4_built_split = 0;
+    Spmm5Operator s5_op;
+    int s5_built = 0;
     // work
     DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -239,6 +242,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->mfma_op.release();
     h->s4_op.release();
+    h->s5_op.release();
     (void)hipStreamDestroy(h->stream);
     delete h;
     return RSREC_OK;
@@ -259,6 +263,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "post")) h->opt_post = value;
     else if (!strcmp(key, "fuse")) h->opt_fuse = value;
     else if (!strcmp(key, "three_term")) h->opt_three = value;
+    else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
     else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -397,6 +402,10 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
                                  (hoh && nmax > 0) ? hallo : nullptr, nsplit);
             if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
             h->s4_built_split = nsplit;
+            msg = h->s5_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
+                                 (hoh && nmax > 0) ? hallo : nullptr);
+            if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
+            h->s5_built = 1;
         }
     }
     h->have_ham = true;
@@ -611,9 +620,14 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int nsteps = lld - 1;
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
-    const int nvec = MFMA ? 4 : (hoh ? 3 : 2);
+    int nvec = MFMA ? 4 : (hoh ? 3 : 2);
     const bool three_term = MFMA && !hoh && h->opt_post != 1 && !h->opt_fuse && h->opt_three;
     const bool u_scheme = three_term && h->opt_three == 2 && h->opt_wps != 2;
+    // SpMM input in the k-pair layout (k_spmm5): the large-launch kernel; small launches keep the cooperative k_spmm4<4>
+    // (spmm5 = 2 forces it)
+    const bool use_kp = u_scheme && h->s5_built && h->opt_spmm4 != 0 &&
+                        (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
+    if (use_kp) nvec = 5;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -675,6 +689,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
         if (u_scheme) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
+        double* ukp = use_kp ? h->d_vec[4].as<double>() : nullptr;
+        if (use_kp) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
@@ -703,6 +719,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
+                    else if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -711,7 +728,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         if (u_scheme) {
                             // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
                             k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
-                            k_mfma_orth3<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                            if (use_kp) k_mfma_orth3<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                            else k_mfma_orth3<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
                             k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                       h->d_status.as<int>());
                             std::swap(psi, t2);
