@@ -36,6 +36,9 @@ __host__ __device__ constexpr int kp_offset(int r, int part, int c) {
     return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
 }
 
+#ifndef S5_PROBE
+#define S5_PROBE 0   // timing probes only: 1 = no operator-fragment loads in the slot loop, 2 = no psi loads (results wrong)
+#endif
 constexpr int S5_FRAG_PER_RB = 320;                         // doubles: pair 0 (128), pair 1 (128), single (64)
 constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][sigma_in][rb]
 
@@ -124,22 +127,36 @@ struct S5Slot {
     unsigned rem;              // remainder tile: byte offset of this lane's neighbour block (per lane: atom l15 >> 1)
 };
 
-template <int P>
+template <int P, bool LOOP = true>
 __device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
                                              unsigned lane_main, unsigned lane_rem, unsigned lane16) {
+    if (!(LOOP && (S5_PROBE & 2))) {
 #pragma unroll
-    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1024 * P);
-    o.b[8] = *reinterpret_cast<const s5_d2*>(inb + spin_off + (S.rem + lane_rem) + 128 * P);
+        for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1024 * P);
+        o.b[8] = *reinterpret_cast<const s5_d2*>(inb + spin_off + (S.rem + lane_rem) + 128 * P);
+    }
+    if (!(LOOP && (S5_PROBE & 1))) {
 #pragma unroll
-    for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
+        for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
+    }
 }
 __device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
                                                unsigned lane_single, unsigned lane_rem_single, unsigned lane8) {
+    if (!(S5_PROBE & 2)) {
 #pragma unroll
-    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const double*>(S.tile[t] + spin_off + lane_single);
-    o.b[8] = *reinterpret_cast<const double*>(inb + spin_off + (S.rem + lane_rem_single));
+        for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const double*>(S.tile[t] + spin_off + lane_single);
+        o.b[8] = *reinterpret_cast<const double*>(inb + spin_off + (S.rem + lane_rem_single));
+    } else {
 #pragma unroll
-    for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const double*>(fb + lane8 + (rb * S5_FRAG_PER_RB * 8 + 2048));
+        for (int t = 0; t < 9; ++t) o.b[t] = 1e-3 * (t + 1);
+    }
+    if (!(S5_PROBE & 1)) {
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const double*>(fb + lane8 + (rb * S5_FRAG_PER_RB * 8 + 2048));
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < 5; ++rb) o.a[rb] = 1e-3 * (rb + 1);
+    }
 }
 
 // issue order: one operand load, then PER MFMAs (see k_spmm4's s4_interleave)
@@ -174,40 +191,42 @@ __device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Sing
 // while the MFMAs of the current one run.
 template <int PAT>
 __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const char* __restrict__ inb,
-                                             const int* __restrict__ nbr, const int (&atom)[GROUP], int nslots, int zero_block, int sig, int l15,
+                                             const int* __restrict__ nbr5 /*(kk+1) x nslots, absent -> zero block*/, const int (&atom)[GROUP] /*padding -> zero block*/,
+                                             unsigned rem_row /*per lane: nslots * atom of the remainder column*/, int nslots, int sig,
                                              unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
     const int nmine = share[0];
     if (nmine <= 0) return;
     constexpr int NH = PAT == 0 ? 2 : 1;
-    auto load_idx = [&](int s, int (&n)[GROUP]) {
+    // neighbour indices: wave-uniform scalar loads for the 8 atom tiles, one per-lane load for the remainder tile; both are
+    // issued a whole slot before they are turned into addresses
+    auto load_idx = [&](int s, int (&n)[GROUP], int& nr) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) n[t] = nbr[(size_t)nslots * max(atom[t], 0) + s];
+        for (int t = 0; t < GROUP; ++t) n[t] = nbr5[(size_t)nslots * atom[t] + s];
+        nr = nbr5[rem_row + (unsigned)s];
     };
-    const int rem_t = l15 >> 1;
-    auto make_slot = [&](const int (&n)[GROUP], S5Slot& S) {
-        int mr = zero_block;
+    auto make_slot = [&](const int (&n)[GROUP], int nr, S5Slot& S) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) {
-            const int m = (atom[t] >= 0 && n[t] >= 0) ? n[t] : zero_block;
-            S.tile[t] = inb + (size_t)m * (BLD * 8);
-            mr = (rem_t == t) ? m : mr;
-        }
-        S.rem = (unsigned)mr * (BLD * 8u);
+        for (int t = 0; t < GROUP; ++t) S.tile[t] = inb + (size_t)n[t] * (BLD * 8);
+        S.rem = (unsigned)nr * (BLD * 8u);
     };
-    auto frag_of = [&](int s, int si) { return reinterpret_cast<const char*>(fr + ((size_t)s * 4 + (sig * 2 + si)) * (5 * S5_FRAG_PER_RB)); };
-    S5Slot cur, nxt;
-    int nraw[GROUP];
+    const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB);
+    auto frag_of = [&](int s, int si) { return reinterpret_cast<const char*>(fr_sig + (size_t)s * S5_FRAG_PER_SLOT + si * (5 * S5_FRAG_PER_RB)); };
+    S5Slot cur;
+    int nraw[GROUP], nrem;
     int s_cur = share[1];
     int s_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
-    load_idx(s_cur, nraw);
-    make_slot(nraw, cur);
+    load_idx(s_cur, nraw, nrem);
+    make_slot(nraw, nrem, cur);
     S5Pair X, Y;
     S5Single Z;
     const int si0 = PAT == 0 ? 0 : sig;
-    s5_load_pair<0>(X, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    s5_load_pair<0, false>(X, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
     for (int j = 0; j < nmine; ++j) {
         const int s_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last slot prefetches the first again (discarded)
-        load_idx(s_nxt, nraw);
+        load_idx(s_nxt, nraw, nrem);
+        // (pinning the 32-bit lane offsets inside the loop makes hipcc emit SGPR-base + VGPR-offset loads, but costs 10 more VGPRs
+        //  -> scratch spills in the group prologue and a 3.5 % slower kernel; measured, not used)
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
             const int si = PAT == 0 ? hh : sig;
@@ -222,8 +241,8 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
             s5_interleave<14, 90>();
             __builtin_amdgcn_sched_barrier(0);
             if (hh == NH - 1) {
-                make_slot(nraw, nxt);
-                s5_load_pair<0>(X, nxt, inb, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
+                make_slot(nraw, nrem, cur);        // the current slot's operands are all in flight or consumed: reuse its state
+                s5_load_pair<0>(X, cur, inb, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
             } else {
                 s5_load_pair<0>(X, cur, inb, 2592u, frag_of(s_cur, 1), lane_main, lane_rem, lane16);
             }
@@ -231,7 +250,6 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
             s5_interleave<14, 45>();
             __builtin_amdgcn_sched_barrier(0);
         }
-        cur = nxt;
         s_cur = s_nxt;
         s_nxt = s_nxt2;
     }
@@ -240,8 +258,9 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  in_kp: KP layout; out: LayoutRM (read by the Gram / orthogonalisation kernels).
 __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
-                                               const int* __restrict__ nbr, const int* __restrict__ izp, const double* __restrict__ frag,
-                                               const int* __restrict__ meta, const double* __restrict__ in_all, double* __restrict__ out_all) {
+                                               const int* __restrict__ nbr /*nbr5: (kk+1) x nslots, absent -> kk*/, const int* __restrict__ izp,
+                                               const double* __restrict__ frag, const int* __restrict__ meta, const double* __restrict__ in_all,
+                                               double* __restrict__ out_all) {
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -274,12 +293,14 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
     }
     for (; g < gend; g += gstep) {
         const int* __restrict__ grp = order + (size_t)g * GROUP;
-        int atom[GROUP];
+        int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the slot loop
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) atom[t] = grp[t];
+        for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; atom[t] = a >= 0 ? a : zero_block; }
         const int first = atom[0];
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
-        const int my_rem_atom = grp[l15 >> 1];
+        int my_rem_atom = grp[l15 >> 1];
+        my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
+        const unsigned rem_row = (unsigned)D.nslots * (unsigned)my_rem_atom;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
         const double* __restrict__ fr = frag + (size_t)tau * D.nslots * S5_FRAG_PER_SLOT;
 
@@ -289,9 +310,8 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
 
-        s5_run_slots<0>(acc, M, fr, inb, nbr, atom, D.nslots, zero_block, sig, l15, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
-        s5_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, inb, nbr, atom, D.nslots, zero_block, sig, l15, lane_main, lane_single, lane_rem, lane_rem_single,
-                        lane16, lane8);
+        s5_run_slots<0>(acc, M, fr, inb, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, inb, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
         // D layout: row w = 4 rb + l4 of spin sig (w = 18, 19: padding, exact zeros, not stored), column l15
 #pragma unroll
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int a = (t < 8) ? atom[t] : my_rem_atom;
-                if (a < 0) continue;
+                if (a == zero_block) continue;
                 out[(size_t)BLD * a + ro + ((t < 8) ? l15 : 16 + (l15 & 1))] = acc[rb][t];
             }
         }

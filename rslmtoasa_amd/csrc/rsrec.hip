@@ -58,7 +58,7 @@ struct rsrec_handle {
     std::vector<int> nbr;        // [kk][nslots] 0-based, -1 absent, slot 0 = self
     std::vector<int> iz0;        // 0-based types
     std::vector<int> radj_ptr, radj;  // reverse adjacency: atoms whose neighbour list contains n
-    DevBuf d_nbr, d_iz;
+    DevBuf d_nbr, d_iz, d_nbr5;   // nbr5: (kk+1) x nslots, absent neighbours and the extra row point at the zero block (k_spmm5)
     // hamiltonian
     int hslots = 0, hoh = 0, nsp = 2;
     DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
@@ -235,7 +235,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&h->d_nbr, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+    DevBuf* all[] = {&h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
@@ -326,6 +326,12 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
     HIPCK(h, h->d_iz.reserve((size_t)kk * sizeof(int)));
     HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
+    {
+        std::vector<int> n5((size_t)(kk + 1) * nslots, kk);
+        for (size_t e = 0; e < h->nbr.size(); ++e) if (h->nbr[e] >= 0) n5[e] = h->nbr[e];
+        HIPCK(h, h->d_nbr5.reserve(n5.size() * sizeof(int)));
+        HIPCK(h, hipMemcpy(h->d_nbr5.p, n5.data(), n5.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     spatial_key_from_graph(h);
     h->have_lattice = true;
     h->lattice_epoch++;
@@ -719,7 +725,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
