@@ -35,9 +35,10 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); ra
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
 # Memory-side bytes per H|psi> launch of the DEFAULT workload (22^3 atoms, 64 sites, LL=50), from separate rocprofv3 --pmc passes
-# (profiles/r01_spmm4_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 35.96 GB + 3.80 GB.
+# (profiles/r01_spmm5_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 36.2 GB + 3.2 GB.
 # The counters sit on the L2's fabric side, so Infinity-Cache hits of the neighbour gathers are included.
-HOP_TRAFFIC_BYTES_PER_LAUNCH = 39.75e9
+HOP_TRAFFIC_BYTES_PER_LAUNCH = 39.4e9
+CPU_SAMPLE_SITES = 6
 BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
 
 
@@ -67,7 +68,8 @@ def cpu_baseline(nn, ee, lsham, lld, threads):
             from oracle import fixture_io as fio
             scratch = tempfile.mkdtemp(prefix="rsrec_cpu_")
             kk = nn.shape[0]
-            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=np.array([1], np.int32), lld=lld, nsp=2, hoh=0, kind=0, ee=ee, lsham=lsham)
+            nsample = CPU_SAMPLE_SITES          # bounded sample: ~10-30 s of CPU work on 16 cores
+            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=spread_sites(kk, nsample), lld=lld, nsp=2, hoh=0, kind=0, ee=ee, lsham=lsham)
             fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G")
             r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=scratch, env=env, capture_output=True, text=True, timeout=600)
@@ -76,8 +78,9 @@ def cpu_baseline(nn, ee, lsham, lld, threads):
                 if "recursion wall time" in line:
                     t = float(line.split()[-2])
             if r.returncode == 0 and t:
-                return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "kind": "reference", "seconds": t,
-                        "sample": "1 site of the same 10648-atom cell, LL=%d (%.1f GFLOP), compiled reference recur_b via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (lld, flop * 1e-9)}
+                return {"value": nsample * flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "kind": "reference", "seconds": t,
+                        "sites_per_s": nsample / t,
+                        "sample": "%d sites of the same %d-atom cell, LL=%d (%.1f GFLOP), compiled reference recur_b via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (nsample, kk, lld, nsample * flop * 1e-9)}
         except Exception as e:  # noqa
             print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
     from oracle import oracle
@@ -200,7 +203,7 @@ def main():
             "device_ms_per_step": tm_acc["total_ms"] / args.steps,
             "host_ms_per_step": tm_acc["host_ms"] / args.steps,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None, "kernel": "k_spmm4 (H|psi> block SpMM, FP64 MFMA 4x4x4)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
+                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None, "kernel": ("k_spmm5" if default_workload else "k_spmm5 / k_spmm4") + " (H|psi> block SpMM, FP64 MFMA 4x4x4)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
                          "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
                                       "note": "whole recursion level, algorithmic 51840 B per atom-step"}},
