@@ -95,6 +95,13 @@ contains
                                 c_loc(this%lattice%nn), c_loc(this%lattice%iz), int(this%lattice%nmax, c_int), &
                                 int(this%lattice%ntype, c_int))
          call check(rc, 'rsrec_set_lattice')
+         ! locality hint only (processing order of the atoms); the arithmetic never reads the positions
+         if (allocated(this%lattice%cr)) then
+            if (size(this%lattice%cr, 1) == 3 .and. size(this%lattice%cr, 2) >= this%lattice%kk) then
+               rc = rsrec_set_positions(g_handle, c_loc(this%lattice%cr))
+               call check(rc, 'rsrec_set_positions')
+            end if
+         end if
       end if
       hoh_i = 0
       if (this%hamiltonian%hoh) hoh_i = 1

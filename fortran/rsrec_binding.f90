@@ -43,6 +43,13 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_set_positions(handle, cr) bind(C, name='rsrec_set_positions') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         type(c_ptr), value :: cr
+         integer(c_int) :: rc
+      end function
+
       function rsrec_set_hamiltonian(handle, nslots, hoh, nsp, ee, lsham, eeo, enim, hall, hallo) &
          bind(C, name='rsrec_set_hamiltonian') result(rc)
          import :: c_int, c_ptr
