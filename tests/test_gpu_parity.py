@@ -13,6 +13,16 @@ from rslmtoasa_amd.recursion import Recursion
 pytestmark = pytest.mark.gpu
 
 KERNELS = [1, 2]   # 1 = VALU reference kernels, 2 = MFMA kernels (both are HIP; both must meet the bar)
+# "kp": MFMA kernels with the large-launch SpMM (k_spmm5, k-pair vector layout) forced on the small fixtures too
+BLOCK_VARIANTS = [1, 2, "kp"]
+
+
+def select_kernels(rec, variant):
+    if variant == "kp":
+        rec.set_option("kernels", 2)
+        rec.set_option("spmm5", 2)
+    else:
+        rec.set_option("kernels", variant)
 
 
 def make(p, irec, lld, **kw):
@@ -20,12 +30,12 @@ def make(p, irec, lld, **kw):
     return Recursion(ham, lat, ctl, en, device=0)
 
 
-@pytest.mark.parametrize("kernels", KERNELS)
+@pytest.mark.parametrize("kernels", BLOCK_VARIANTS)
 @pytest.mark.parametrize("name", BLOCK_CASES)
 def test_block_lanczos_golden(name, kernels, oracle_lib):
     g = load_golden(name)
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
-    rec.set_option("kernels", kernels)
+    select_kernels(rec, kernels)
     rec.recur_b()
     n = g["nrec"]
     assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL
@@ -128,6 +138,24 @@ def test_config1_full_size_vs_reference(kernels):
         m = rec.b2_b[:, :, ll, 0]
         assert np.abs(m @ m - b2_before[:, :, ll, 0]).max() < 1e-13
         assert np.abs(m - m.conj().T).max() < 1e-13
+    rec.close()
+
+
+@pytest.mark.parametrize("opts", [{"three_term": 0}, {"three_term": 1}, {"three_term": 2, "spmm4": 1}, {"three_term": 2, "spmm4": 4},
+                                  {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}])
+@pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
+def test_every_block_pipeline_variant(name, opts):
+    """The alternative pipelines kept in the library (reference order, normalised three-term, un-normalised; each SpMM kernel)
+    all meet the bar on a bulk and an impurity fixture."""
+    g = load_golden(name)
+    rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
+    rec.set_option("kernels", 2)
+    for k, v in opts.items():
+        rec.set_option(k, v)
+    rec.recur_b()
+    n = g["nrec"]
+    assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL
+    assert rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]) < RTOL
     rec.close()
 
 
