@@ -222,4 +222,135 @@ __global__ void k_uscheme_init(double2* Bmats, double* tabs) {
     for (int e = threadIdx.x; e < 2 * 27 * 64; e += blockDim.x) tabs[((size_t)chain * 3 + 1) * 27 * 64 + e] = 0.0;
 }
 
+
+// ======================================================================================================================
+// Chebyshev step on the matrix cores (chebyshev_recur_ll, recursion.f90:2495-2597; cheb_1st_mom :2169-2238).
+// The SpMM kernel leaves t = H psi1 in a vector; this kernel does everything after it in ONE pass over the active blocks:
+//   FIRST:  psi1 = (t - b psi0) / a                      ; G2 = sum psi0^H psi1                       (:2228-2236)
+//   else :  psi2 = ((t - b psi1) / a) * 2 - psi0         ; G1 = sum psi1^H psi1, G2 = sum psi2^H psi1 (:2548-2587)
+// in the reference's operation order.  The new vector is written in LayoutRM and, if KP, in the k-pair layout that
+// k_spmm5 reads.  The 18x18 complex reductions are real 36x36 Gram matrices with the stacked rows as MFMA K dimension
+// (same construction as k_mfma_adot); partial[chain][workgroup][2][1296].
+// ======================================================================================================================
+template <bool FIRST, bool KP>
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
+                                                               const double* __restrict__ cur_all, const double* __restrict__ old_all,
+                                                               double* __restrict__ out_all, double a, double b, double* partial,
+                                                               double* __restrict__ okp_all = nullptr) {
+    __shared__ double lds[MF_WAVES * 1296];
+    __shared__ unsigned short kpt[KP ? BLD : 1];
+    if (KP) {
+        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
+        __syncthreads();
+    }
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain, level);
+    const size_t vo = (size_t)chain * CV.vstride;
+    const double* tv = tvec + vo;
+    const double* cu = cur_all + vo;
+    const double* ol = FIRST ? nullptr : old_all + vo;
+    double* out = out_all + vo;
+    double* okp = KP ? okp_all + vo : nullptr;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+    GramAcc G1, G2;
+    G1.zero(); G2.zero();
+    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+        const int* grp = order + (size_t)w.g * GROUP;
+#pragma unroll 2
+        for (int kq = 0; kq < 36; ++kq) {
+            const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);
+            const double t0 = tv[rk.off + l15], t1 = tv[rk.off + 16 + l15], tr = tv[rk.off + 32 + l3];
+            const double c0 = cu[rk.off + l15], c1 = cu[rk.off + 16 + l15], cr = cu[rk.off + 32 + l3];
+            double n0 = (t0 - b * c0) / a, n1 = (t1 - b * c1) / a, nr = (tr - b * cr) / a;
+            if (!FIRST) {
+                const double z0 = ol[rk.off + l15], z1 = ol[rk.off + 16 + l15], zr = ol[rk.off + 32 + l3];
+                n0 = n0 * 2.0 - z0; n1 = n1 * 2.0 - z1; nr = nr * 2.0 - zr;
+            }
+            if (rk.valid) {
+                out[rk.off + l15] = n0; out[rk.off + 16 + l15] = n1;
+                if (lg == 0) out[rk.off + 32 + l3] = nr;
+                if (KP) {
+                    const unsigned blk = (rk.off / BLD) * BLD, e0 = rk.off - blk;
+                    okp[blk + kpt[e0 + l15]] = n0; okp[blk + kpt[e0 + 16 + l15]] = n1;
+                    if (lg == 0) okp[blk + kpt[e0 + 32 + l3]] = nr;
+                }
+            }
+            if (FIRST) {          // G2 = psi0hat^T psi1hat
+                G2.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, n0, G2.t00, 0, 0, 0);
+                G2.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, n1, G2.t01, 0, 0, 0);
+                G2.t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, n0, G2.t10, 0, 0, 0);
+                G2.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, n1, G2.t11, 0, 0, 0);
+                G2.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, n0, G2.tr0, 0, 0, 0);
+                G2.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, n1, G2.tr1, 0, 0, 0);
+                G2.t0r = __builtin_amdgcn_mfma_f64_4x4x4f64(c0, nr, G2.t0r, 0, 0, 0);
+                G2.t1r = __builtin_amdgcn_mfma_f64_4x4x4f64(c1, nr, G2.t1r, 0, 0, 0);
+                G2.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, nr, G2.trr, 0, 0, 0);
+            } else {              // G1 = psi1hat^T psi1hat (symmetric half), G2 = psi2hat^T psi1hat
+                G1.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, c0, G1.t00, 0, 0, 0);
+                G1.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, c1, G1.t01, 0, 0, 0);
+                G1.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, c1, G1.t11, 0, 0, 0);
+                G1.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, c0, G1.tr0, 0, 0, 0);
+                G1.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, c1, G1.tr1, 0, 0, 0);
+                G1.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, cr, G1.trr, 0, 0, 0);
+                G2.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, c0, G2.t00, 0, 0, 0);
+                G2.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, c1, G2.t01, 0, 0, 0);
+                G2.t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, c0, G2.t10, 0, 0, 0);
+                G2.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, c1, G2.t11, 0, 0, 0);
+                G2.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(nr, c0, G2.tr0, 0, 0, 0);
+                G2.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(nr, c1, G2.tr1, 0, 0, 0);
+                G2.t0r = __builtin_amdgcn_mfma_f64_4x4x4f64(n0, cr, G2.t0r, 0, 0, 0);
+                G2.t1r = __builtin_amdgcn_mfma_f64_4x4x4f64(n1, cr, G2.t1r, 0, 0, 0);
+                G2.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(nr, cr, G2.trr, 0, 0, 0);
+            }
+        }
+    }
+    double* pout = partial + ((size_t)chain * gridDim.x + blockIdx.x) * 2 * 1296;
+    gram_block_out(G1, lds, pout, true);
+    __syncthreads();
+    gram_block_out(G2, lds, pout + 1296, false);
+}
+
+// 36x36 Gram partials of k_mfma_cheb -> moments.  first: mu[1] = sum psi0^H psi1.  else: mu[2ll] = 2 d1 - mu[0],
+// mu[2ll+1] = 2 d2 - mu[1] (0-based moment index; recursion.f90:2591-2592) and the divergence test of :2594 / :2484.
+__global__ __launch_bounds__(1024) void k_reduce_cheb_mf(const double* __restrict__ partial, int nblk, int first, int ll, double2* mu, size_t mustride,
+                                                        int* status, int check_both) {
+    __shared__ double img[2][1296];
+    __shared__ double tr[2][BLK];
+    const int chain = blockIdx.x, tid = threadIdx.x;
+    const double* P = partial + (size_t)chain * nblk * 2 * 1296;
+    for (int e = tid; e < 2 * 1296; e += blockDim.x) {
+        const int which = e / 1296, k = e % 1296;
+        double s = 0.0;
+        for (int p = 0; p < nblk; ++p) s += P[((size_t)p * 2 + which) * 1296 + k];
+        img[which][k] = s;
+    }
+    __syncthreads();
+    double2* m = mu + chain * mustride;
+    if (tid < BLK) {
+        const int cp = tid % NB, cc = tid / NB;
+        const double2 d1 = make_double2(img[0][36 * cp + cc] + img[0][36 * (18 + cp) + 18 + cc], img[0][36 * cp + 18 + cc] - img[0][36 * (18 + cp) + cc]);
+        const double2 d2 = make_double2(img[1][36 * cp + cc] + img[1][36 * (18 + cp) + 18 + cc], img[1][36 * cp + 18 + cc] - img[1][36 * (18 + cp) + cc]);
+        if (first) {
+            m[BLK + tid] = d2;
+            tr[0][tid] = 0.0; tr[1][tid] = 0.0;
+        } else {
+            const double2 m0 = m[tid], m1 = m[BLK + tid];
+            const double2 o1 = make_double2(2.0 * d1.x - m0.x, 2.0 * d1.y - m0.y);
+            const double2 o2 = make_double2(2.0 * d2.x - m1.x, 2.0 * d2.y - m1.y);
+            m[(size_t)(2 * ll) * BLK + tid] = o1;
+            m[(size_t)(2 * ll + 1) * BLK + tid] = o2;
+            tr[0][tid] = o2.x; tr[1][tid] = o1.x;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && !first) {
+        double s = 0.0, s1 = 0.0;
+        for (int e = 0; e < BLK; ++e) { s += tr[0][e]; s1 += tr[1][e]; }
+        if (s > 1000.0 || (check_both && s1 > 1000.0)) atomicOr(status, 2);
+    }
+}
+
 }  // namespace rsrec

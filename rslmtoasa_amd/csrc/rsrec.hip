@@ -866,13 +866,18 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const int nlev = (hoh ? 2 * napply : napply) + 1;
     const int nmom = 2 * lld + 2;
     const size_t velems = (size_t)(kk + 1) * BLD;
-    const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
+    // matrix-core epilogue (k_mfma_cheb) and, for large launches, the k-pair SpMM input (k_spmm5): plain Chebyshev only;
+    // hoh keeps the VALU combine kernels
+    const bool mf_cheb = MFMA && !hoh && h->opt_post != 1;
+    const bool use_kp = mf_cheb && h->s5_built && h->opt_spmm4 != 0 &&
+                        (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096));
+    const int nvec = MFMA ? ((hoh || use_kp) ? 5 : 4) : (hoh ? 4 : 3);
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
-    HIPCK(h, h->d_partial.reserve((size_t)B * nblk * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_partial.reserve(std::max((size_t)B * nblk * 2 * BLK * sizeof(double2), (size_t)B * 256 * 2 * 1296 * sizeof(double))));
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
@@ -923,7 +928,9 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         double* tmp2 = h->d_vec[4].as<double>();
         const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
-        k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)                                   // mu_1 = psi0^H psi0 = I (cheb_0th_mom :2157)
+        k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)
+        double* vkp = use_kp ? tmp2 : nullptr;                  // k-pair copy of the vector the next SpMM reads
+        if (use_kp) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, p0, vkp);
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
             const bool first = (t == 1);
@@ -934,6 +941,25 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             G.a = a; G.b = b;
             double* src = first ? p0 : p1;
             double* dst = first ? p1 : p2;
+            if (mf_cheb) {
+                const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
+                if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
+                hipEvent_t e1 = next_event(h);
+                hop_ev.emplace_back(e0, e1);
+                h->n_hop_launch += 1;
+                double* gp = h->d_partial.as<double>();
+                if (first) {
+                    if (use_kp) k_mfma_cheb<true, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
+                    else k_mfma_cheb<true, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
+                } else {
+                    if (use_kp) k_mfma_cheb<false, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
+                    else k_mfma_cheb<false, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
+                }
+                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp, grid_mf.x, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
+                continue;
+            }
             if (MFMA) {
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems, CV.obase};
                 rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc;

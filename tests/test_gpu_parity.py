@@ -51,12 +51,12 @@ def test_block_lanczos_golden(name, kernels, oracle_lib):
     rec.close()
 
 
-@pytest.mark.parametrize("kernels", KERNELS)
+@pytest.mark.parametrize("kernels", BLOCK_VARIANTS)
 @pytest.mark.parametrize("name", CHEB_CASES)
 def test_chebyshev_golden(name, kernels):
     g = load_golden(name)
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], emin=g["emin"], emax=g["emax"])
-    rec.set_option("kernels", kernels)
+    select_kernels(rec, kernels)
     rec.chebyshev_recur()
     assert rel_err(rec.mu_n[:, :, :, : g["nrec"]], g["mu_n"]) < RTOL
     rec.close()
@@ -171,7 +171,7 @@ def test_batching_is_invisible():
     rec.close()
 
 
-@pytest.mark.parametrize("kernels", KERNELS)
+@pytest.mark.parametrize("kernels", BLOCK_VARIANTS)
 @pytest.mark.parametrize("name", PAIR_CASES)
 def test_pair_variants_golden(name, kernels):
     """recur_b_ij / chebyshev_recur_ij (recursion.f90:1655 / :2376): four chains per pair, against the compiled reference."""
@@ -180,7 +180,7 @@ def test_pair_variants_golden(name, kernels):
     ham, lat, ctl, en = objects_from(p, [1], int(g["lld"]), emin=float(g["emin"]), emax=float(g["emax"]))
     lat.ijpair = np.asarray(g["pairs"], dtype=np.int32)
     rec = Recursion(ham, lat, ctl, en)
-    rec.set_option("kernels", kernels)
+    select_kernels(rec, kernels)
     if "cheb" in name:
         rec.chebyshev_recur_ij()
         assert rel_err(rec.mu_n, g["mu_n"]) < RTOL
