@@ -43,7 +43,7 @@ constexpr int S5_FRAG_PER_RB = 320;                         // doubles: pair 0 (
 constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][sigma_in][rb]
 
 struct Spmm5Operator {
-    double* d_frag = nullptr;    // [set][tau][slot][sigma_out][sigma_in][rb][320]
+    double* d_frag = nullptr;    // [set][tau][slot 0..nslots][sigma_out][sigma_in][rb][320]
     int* d_meta = nullptr;       // [set][tau][pattern][1 + S4_MAXSLOTS]: slot lists (0 = spin-mixing, 1 = spin-diagonal)
     size_t frag_bytes = 0, meta_bytes = 0;
     int ntau = 0, nslots = 0, have_o = 0;
@@ -77,21 +77,39 @@ struct Spmm5Operator {
                     }
                 }
     }
-    const char* build(int nslots_lat, int hstride, int ntype, int nmax, int hoh, const double* st, const double* loc, const double* eeo, const double* hallo) {
-        if (nslots_lat > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
+    // Set 0: the blocks of h (slot 0 carries + l.s when !hoh).  Set 1 (hoh second pass) is built so that ONE SpMM pass over
+    // hpsi = h psi plus one extra on-site slot reading psi gives the whole  H psi = hpsi - (h o) hpsi + (e_nu + l.s) psi
+    // (recursion.f90:1543):  slot 0 -> 1 - (h o)_0,  slot s -> -(h o)_s,  slot `nslots` (extra) -> enim + lsham of the atom's type.
+    // Every tau has nslots + 1 fragment slots in both sets (the extra one stays zero and unlisted in set 0).
+    const char* build(int nslots_lat, int hstride, int ntype, int nmax, int hoh, const double* st, const double* loc, const double* eeo, const double* hallo,
+                      const double* enim, const double* lsham, const int* iz0) {
+        if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
         ntau = nmax + ntype; nslots = nslots_lat; have_o = hoh ? 1 : 0;
         const int nset = have_o ? 2 : 1;
-        const size_t per_set = (size_t)ntau * nslots * S5_FRAG_PER_SLOT;
+        const int nfs = nslots + 1;
+        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT;
         std::vector<double> host(per_set * nset, 0.0);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
+        std::vector<double> tmp(2 * BLK);
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
                 int* M = meta.data() + ((size_t)set * ntau + tau) * META;
-                for (int s = 0; s < nslots; ++s) {
+                for (int s = 0; s < nslots + (set ? 1 : 0); ++s) {
                     const double* src;
-                    if (tau < nmax) src = (set ? hallo : loc) + 2 * (size_t)BLK * (s + (size_t)hstride * tau);
-                    else src = (set ? eeo : st) + 2 * (size_t)BLK * (s + (size_t)hstride * (tau - nmax));
-                    swizzle(src, host.data() + set * per_set + ((size_t)tau * nslots + s) * S5_FRAG_PER_SLOT);
+                    if (s == nslots) {
+                        const int ty = tau < nmax ? iz0[tau] : tau - nmax;
+                        for (int e = 0; e < 2 * BLK; ++e) tmp[e] = enim[2 * (size_t)BLK * ty + e] + lsham[2 * (size_t)BLK * ty + e];
+                        src = tmp.data();
+                    } else {
+                        if (tau < nmax) src = (set ? hallo : loc) + 2 * (size_t)BLK * (s + (size_t)hstride * tau);
+                        else src = (set ? eeo : st) + 2 * (size_t)BLK * (s + (size_t)hstride * (tau - nmax));
+                        if (set) {
+                            for (int e = 0; e < 2 * BLK; ++e) tmp[e] = -src[e];
+                            if (s == 0) for (int d = 0; d < NB; ++d) tmp[2 * (d + NB * d)] += 1.0;
+                            src = tmp.data();
+                        }
+                    }
+                    swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
                     int* W = M + Spmm4Operator::pattern_of(src) * (1 + S4_MAXSLOTS);
                     W[1 + W[0]] = s; W[0]++;
                 }
@@ -113,7 +131,7 @@ struct Spmm5Operator {
         if (hipMemcpy(d_meta, meta.data(), mneed, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 schedule failed";
         return nullptr;
     }
-    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * nslots * S5_FRAG_PER_SLOT; }
+    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * (nslots + 1) * S5_FRAG_PER_SLOT; }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
 };
 
@@ -124,28 +142,29 @@ struct S5Single { double b[9]; double a[5]; };  // the spin's fifth k-step (rows
 // wave-uniform addressing state of one neighbour slot
 struct S5Slot {
     const char* tile[GROUP];   // KP block of the neighbour of atom t (spin 0 half)
+    const char* base;          // vector the slot reads (the second input for the extra on-site slot of the hoh second pass)
     unsigned rem;              // remainder tile: byte offset of this lane's neighbour block (per lane: atom l15 >> 1)
 };
 
 template <int P, bool LOOP = true>
-__device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
+__device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
                                              unsigned lane_main, unsigned lane_rem, unsigned lane16) {
     if (!(LOOP && (S5_PROBE & 2))) {
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1024 * P);
-        o.b[8] = *reinterpret_cast<const s5_d2*>(inb + spin_off + (S.rem + lane_rem) + 128 * P);
+        o.b[8] = *reinterpret_cast<const s5_d2*>(S.base + spin_off + (S.rem + lane_rem) + 128 * P);
     }
     if (!(LOOP && (S5_PROBE & 1))) {
 #pragma unroll
         for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
     }
 }
-__device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, const char* __restrict__ inb, unsigned spin_off, const char* __restrict__ fb,
+__device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
                                                unsigned lane_single, unsigned lane_rem_single, unsigned lane8) {
     if (!(S5_PROBE & 2)) {
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const double*>(S.tile[t] + spin_off + lane_single);
-        o.b[8] = *reinterpret_cast<const double*>(inb + spin_off + (S.rem + lane_rem_single));
+        o.b[8] = *reinterpret_cast<const double*>(S.base + spin_off + (S.rem + lane_rem_single));
     } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.b[t] = 1e-3 * (t + 1);
@@ -189,24 +208,30 @@ __device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Sing
 // All slots of one pattern for one wave (output spin `sig`).  PAT = 1: the slot only couples equal spins (input spin = sig);
 // PAT = 0: both input spins.  Steps per (slot, input spin): pair 0, pair 1, single; the operands of the next step are loaded
 // while the MFMAs of the current one run.
-template <int PAT>
+// TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot of the hoh second pass; it reads the second
+// input vector in2b (recursion.f90:1543: H psi = h psi - (h o)(h psi) + (e_nu + l.s) psi, the last term acts on psi itself).
+template <int PAT, bool TWO>
 __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const char* __restrict__ inb,
-                                             const int* __restrict__ nbr5 /*(kk+1) x nslots, absent -> zero block*/, const int (&atom)[GROUP] /*padding -> zero block*/,
-                                             unsigned rem_row /*per lane: nslots * atom of the remainder column*/, int nslots, int sig,
+                                             const char* __restrict__ in2b, const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
+                                             const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
+                                             int nslots, int sig,
                                              unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
     const int nmine = share[0];
     if (nmine <= 0) return;
     constexpr int NH = PAT == 0 ? 2 : 1;
+    const int nstride = nslots + 1;
     // neighbour indices: wave-uniform scalar loads for the 8 atom tiles, one per-lane load for the remainder tile; both are
     // issued a whole slot before they are turned into addresses
     auto load_idx = [&](int s, int (&n)[GROUP], int& nr) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) n[t] = nbr5[(size_t)nslots * atom[t] + s];
+        for (int t = 0; t < GROUP; ++t) n[t] = nbr5[(size_t)nstride * atom[t] + s];
         nr = nbr5[rem_row + (unsigned)s];
     };
-    auto make_slot = [&](const int (&n)[GROUP], int nr, S5Slot& S) {
+    auto make_slot = [&](const int (&n)[GROUP], int nr, S5Slot& S, int s) {
+        const char* base = (TWO && s == nslots) ? in2b : inb;
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) S.tile[t] = inb + (size_t)n[t] * (BLD * 8);
+        for (int t = 0; t < GROUP; ++t) S.tile[t] = base + (size_t)n[t] * (BLD * 8);
+        S.base = base;
         S.rem = (unsigned)nr * (BLD * 8u);
     };
     const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB);
@@ -216,12 +241,12 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     int s_cur = share[1];
     int s_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
     load_idx(s_cur, nraw, nrem);
-    make_slot(nraw, nrem, cur);
+    make_slot(nraw, nrem, cur, s_cur);
     S5Pair X, Y;
     S5Single Z;
     const int si0 = PAT == 0 ? 0 : sig;
-    s5_load_pair<0, false>(X, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
-    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, inb, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    s5_load_pair<0, false>(X, cur, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
     for (int j = 0; j < nmine; ++j) {
         const int s_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last slot prefetches the first again (discarded)
         load_idx(s_nxt, nraw, nrem);
@@ -232,19 +257,19 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
             const int si = PAT == 0 ? hh : sig;
             const unsigned so = 2592u * si;
             const char* __restrict__ fb = frag_of(s_cur, si);
-            s5_load_pair<1>(Y, cur, inb, so, fb, lane_main, lane_rem, lane16);
+            s5_load_pair<1>(Y, cur, so, fb, lane_main, lane_rem, lane16);
             s5_mfma_pair(acc, X);
             s5_interleave<14, 90>();
             __builtin_amdgcn_sched_barrier(0);
-            s5_load_single(Z, cur, inb, so, fb, lane_single, lane_rem_single, lane8);
+            s5_load_single(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
             s5_mfma_pair(acc, Y);
             s5_interleave<14, 90>();
             __builtin_amdgcn_sched_barrier(0);
             if (hh == NH - 1) {
-                make_slot(nraw, nrem, cur);        // the current slot's operands are all in flight or consumed: reuse its state
-                s5_load_pair<0>(X, cur, inb, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
+                make_slot(nraw, nrem, cur, s_nxt);        // the current slot's operands are all in flight or consumed: reuse its state
+                s5_load_pair<0>(X, cur, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
             } else {
-                s5_load_pair<0>(X, cur, inb, 2592u, frag_of(s_cur, 1), lane_main, lane_rem, lane16);
+                s5_load_pair<0>(X, cur, 2592u, frag_of(s_cur, 1), lane_main, lane_rem, lane16);
             }
             s5_mfma_single(acc, Z);
             s5_interleave<14, 45>();
@@ -257,10 +282,14 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  in_kp: KP layout; out: LayoutRM (read by the Gram / orthogonalisation kernels).
+// OUT_KP: write the result in the KP layout instead (first pass of hoh: its result is only read by the second pass).
+// TWO: second input vector for the extra on-site slot (second pass of hoh).
+template <bool OUT_KP, bool TWO>
 __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
-                                               const int* __restrict__ nbr /*nbr5: (kk+1) x nslots, absent -> kk*/, const int* __restrict__ izp,
-                                               const double* __restrict__ frag, const int* __restrict__ meta, const double* __restrict__ in_all,
-                                               double* __restrict__ out_all) {
+                                               const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
+                                               const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
+                                               const double* __restrict__ in_all, double* __restrict__ out_all,
+                                               const double* __restrict__ in2_all = nullptr) {
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -270,6 +299,7 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
     const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
     const size_t vo = (size_t)chain * D.vstride;
     const char* __restrict__ inb = reinterpret_cast<const char*>(in_all + vo);
+    const char* __restrict__ in2b = TWO ? reinterpret_cast<const char*>(in2_all + vo) : nullptr;
     double* __restrict__ out = out_all + vo;
     const int zero_block = D.kk;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -300,9 +330,9 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
         int my_rem_atom = grp[l15 >> 1];
         my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
-        const unsigned rem_row = (unsigned)D.nslots * (unsigned)my_rem_atom;
+        const unsigned rem_row = (unsigned)(D.nslots + 1) * (unsigned)my_rem_atom;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
-        const double* __restrict__ fr = frag + (size_t)tau * D.nslots * S5_FRAG_PER_SLOT;
+        const double* __restrict__ fr = frag + (size_t)tau * (D.nslots + 1) * S5_FRAG_PER_SLOT;
 
         double acc[5][9];
 #pragma unroll
@@ -310,20 +340,46 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
 
-        s5_run_slots<0>(acc, M, fr, inb, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
-        s5_run_slots<1>(acc, M + (1 + S4_MAXSLOTS), fr, inb, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_slots<0, TWO>(acc, M, fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_slots<1, TWO>(acc, M + (1 + S4_MAXSLOTS), fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single,
+                             lane16, lane8);
 
         // D layout: row w = 4 rb + l4 of spin sig (w = 18, 19: padding, exact zeros, not stored), column l15
+        if (!OUT_KP) {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) {
-            const int w = 4 * rb + l4;
-            if (w >= 18) continue;
-            const int ro = 36 * (9 * sig + (w % 9)) + 18 * (w / 9);
+            for (int rb = 0; rb < 5; ++rb) {
+                const int w = 4 * rb + l4;
+                if (w >= 18) continue;
+                const int ro = 36 * (9 * sig + (w % 9)) + 18 * (w / 9);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int a = (t < 8) ? atom[t] : my_rem_atom;
+                    if (a == zero_block) continue;
+                    out[(size_t)BLD * a + ro + ((t < 8) ? l15 : 16 + (l15 & 1))] = acc[rb][t];
+                }
+            }
+        } else {
+            // KP layout: row blocks (2p, 2p+1) are the two members of k-pair p -> one 16-byte store; rb = 4 is the single k-step
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int a = (t < 8) ? atom[t] : my_rem_atom;
                 if (a == zero_block) continue;
-                out[(size_t)BLD * a + ro + ((t < 8) ? l15 : 16 + (l15 & 1))] = acc[rb][t];
+                double* ob = out + (size_t)BLD * a + 324 * sig;
+                if (t < 8) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
+                        *reinterpret_cast<s5_d2*>(ob + 128 * p + 32 * l4 + 2 * l15) = v;
+                    }
+                    if (l4 < 2) ob[256 + 16 * l4 + l15] = acc[4][t];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
+                        *reinterpret_cast<s5_d2*>(ob + 288 + 16 * p + 4 * l4 + 2 * (l15 & 1)) = v;
+                    }
+                    if (l4 < 2) ob[320 + 2 * l4 + (l15 & 1)] = acc[4][t];
+                }
             }
         }
     }

@@ -68,7 +68,7 @@ struct rsrec_handle {
     Spmm5Operator s5_op;
     int s5_built = 0;
     // work
-    DevBuf d_frags, d_vec[5], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
+    DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
@@ -236,7 +236,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
-                     &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
+                     &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
@@ -327,8 +327,12 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
     HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
     {
-        std::vector<int> n5((size_t)(kk + 1) * nslots, kk);
-        for (size_t e = 0; e < h->nbr.size(); ++e) if (h->nbr[e] >= 0) n5[e] = h->nbr[e];
+        // (kk+1) x (nslots+1): absent neighbours and the extra row -> zero block; last column = the atom itself (extra on-site slot)
+        std::vector<int> n5((size_t)(kk + 1) * (nslots + 1), kk);
+        for (int i = 0; i < kk; ++i) {
+            for (int j = 0; j < nslots; ++j) { const int n = h->nbr[(size_t)i * nslots + j]; if (n >= 0) n5[(size_t)i * (nslots + 1) + j] = n; }
+            n5[(size_t)i * (nslots + 1) + nslots] = i;
+        }
         HIPCK(h, h->d_nbr5.reserve(n5.size() * sizeof(int)));
         HIPCK(h, hipMemcpy(h->d_nbr5.p, n5.data(), n5.size() * sizeof(int), hipMemcpyHostToDevice));
     }
@@ -402,14 +406,14 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
         const char* msg = h->mfma_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
                                            (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham);
         if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
-        if (h->nslots <= S4_MAXSLOTS) {
+        if (h->nslots + 1 <= S4_MAXSLOTS) {
             const int nsplit = 1;
             msg = h->s4_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
                                  (hoh && nmax > 0) ? hallo : nullptr, nsplit);
             if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
             h->s4_built_split = nsplit;
             msg = h->s5_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
-                                 (hoh && nmax > 0) ? hallo : nullptr);
+                                 (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham, h->iz0.data());
             if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
             h->s5_built = 1;
         }
@@ -633,7 +637,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     // (spmm5 = 2 forces it)
     const bool use_kp = u_scheme && h->s5_built && h->opt_spmm4 != 0 &&
                         (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
-    if (use_kp) nvec = 5;
+    // hoh on the un-normalised scheme: both SpMM passes in k_spmm5 (first pass writes KP, second pass adds the on-site
+    // e_nu + l.s term from psi through its extra slot), then the same post-hop kernels as without hoh
+    const bool u_hoh = MFMA && hoh && h->opt_post != 1 && h->opt_three == 2 && h->opt_wps != 2 && h->s5_built && h->opt_spmm5 >= 1 && h->opt_spmm4 != 0;
+    if (use_kp || u_hoh) nvec = 5;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -694,9 +701,9 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (the three-term scheme swaps them every level)
         k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
-        if (u_scheme) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
-        double* ukp = use_kp ? h->d_vec[4].as<double>() : nullptr;
-        if (use_kp) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
+        if (u_scheme || u_hoh) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
+        double* ukp = (use_kp || u_hoh) ? h->d_vec[4].as<double>() : nullptr;
+        if (use_kp || u_hoh) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
@@ -725,7 +732,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<false, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -767,6 +774,22 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                     e1 = next_event(h);
                 }
+            } else if (u_hoh) {
+                double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
+                k_spmm5<true, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
+                SD.level = lv_final;
+                k_spmm5<false, true><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
+                e1 = next_event(h);
+                k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                k_mfma_orth3<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                          h->d_status.as<int>());
+                std::swap(psi, t2);
+                hop_ev.emplace_back(e0, e1);
+                h->n_hop_launch += 2;
+                continue;
             } else if (MFMA) {
                 // hoh on the matrix cores: t1 = h psi, t2 = (h o) t1, then the per-atom combine/epilogue (VALU) and MFMA orth/update
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
@@ -868,10 +891,12 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const size_t velems = (size_t)(kk + 1) * BLD;
     // matrix-core epilogue (k_mfma_cheb) and, for large launches, the k-pair SpMM input (k_spmm5): plain Chebyshev only;
     // hoh keeps the VALU combine kernels
-    const bool mf_cheb = MFMA && !hoh && h->opt_post != 1;
-    const bool use_kp = mf_cheb && h->s5_built && h->opt_spmm4 != 0 &&
-                        (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096));
-    const int nvec = MFMA ? ((hoh || use_kp) ? 5 : 4) : (hoh ? 4 : 3);
+    const bool s5_ok = h->s5_built && h->opt_spmm4 != 0 && h->opt_spmm5 >= 1;
+    const bool mf_cheb = MFMA && h->opt_post != 1 && (!hoh || s5_ok);
+    // hoh always takes k_spmm5 (its second pass folds the on-site terms in); plain Chebyshev only for large launches
+    const bool use_kp = mf_cheb && s5_ok &&
+                        (hoh || h->opt_spmm5 == 2 || (h->opt_spmm4 < 0 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096));
+    const int nvec = MFMA ? (hoh ? (mf_cheb ? 6 : 5) : (use_kp ? 5 : 4)) : (hoh ? 4 : 3);
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -930,6 +955,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)
         double* vkp = use_kp ? tmp2 : nullptr;                  // k-pair copy of the vector the next SpMM reads
+        double* hkp = (use_kp && hoh) ? h->d_vec[5].as<double>() : nullptr;   // hoh: k-pair copy of h psi (first pass -> second pass)
         if (use_kp) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, p0, vkp);
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
@@ -942,12 +968,17 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             double* src = first ? p0 : p1;
             double* dst = first ? p1 : p2;
             if (mf_cheb) {
-                const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
-                if (use_kp) k_spmm5<<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
+                if (hoh) {
+                    SD.level = 2 * t - 1;
+                    k_spmm5<true, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
+                    SD.level = lv_final;
+                    k_spmm5<false, true><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
+                } else if (use_kp) k_spmm5<false, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
-                h->n_hop_launch += 1;
+                h->n_hop_launch += hoh ? 2 : 1;
                 double* gp = h->d_partial.as<double>();
                 if (first) {
                     if (use_kp) k_mfma_cheb<true, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
