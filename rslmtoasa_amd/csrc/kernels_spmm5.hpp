@@ -44,10 +44,10 @@ constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][si
 
 struct Spmm5Operator {
     double* d_frag = nullptr;    // [set][tau][slot 0..nslots][sigma_out][sigma_in][rb][320]
-    int* d_meta = nullptr;       // [set][tau][pattern][1 + S4_MAXSLOTS]: slot lists (0 = spin-mixing, 1 = spin-diagonal)
+    int* d_meta = nullptr;       // [set][tau][1 + 2 S4_MAXSLOTS]: count, then entries slot | flip << 8 (flip: input spin = the other spin)
     size_t frag_bytes = 0, meta_bytes = 0;
     int ntau = 0, nslots = 0, have_o = 0;
-    static constexpr int META = 2 * (1 + S4_MAXSLOTS);
+    static constexpr int META = 1 + 2 * S4_MAXSLOTS;
 
     void release() {
         if (d_frag) (void)hipFree(d_frag);
@@ -110,8 +110,9 @@ struct Spmm5Operator {
                         }
                     }
                     swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
-                    int* W = M + Spmm4Operator::pattern_of(src) * (1 + S4_MAXSLOTS);
-                    W[1 + W[0]] = s; W[0]++;
+                    // schedule: the spin-diagonal part of every block, plus the spin-flip part of blocks that have one
+                    M[1 + M[0]] = s; M[0]++;
+                    if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
                 }
             }
         const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
@@ -205,12 +206,13 @@ __device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Sing
         for (int t = 0; t < 9; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb], o.b[t], acc[rb][t], 0, 0, 0);
 }
 
-// All slots of one pattern for one wave (output spin `sig`).  PAT = 1: the slot only couples equal spins (input spin = sig);
-// PAT = 0: both input spins.  Steps per (slot, input spin): pair 0, pair 1, single; the operands of the next step are loaded
-// while the MFMAs of the current one run.
+// All schedule entries of a group for one wave (output spin `sig`).  An entry = (neighbour slot, flip): the wave multiplies
+// the slot's [sig][si] quadrant with input spin si = sig (spin-diagonal part; the only entry of a collinear hopping block)
+// or si = 1 - sig (spin-flip part of the spin-orbit / non-collinear blocks).  Three steps per entry: k-pair 0, k-pair 1,
+// single k-step; the operands of the next step are loaded while the MFMAs of the current one run.
 // TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot of the hoh second pass; it reads the second
 // input vector in2b (recursion.f90:1543: H psi = h psi - (h o)(h psi) + (e_nu + l.s) psi, the last term acts on psi itself).
-template <int PAT, bool TWO>
+template <bool TWO>
 __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const char* __restrict__ inb,
                                              const char* __restrict__ in2b, const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
@@ -218,10 +220,9 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
                                              unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
     const int nmine = share[0];
     if (nmine <= 0) return;
-    constexpr int NH = PAT == 0 ? 2 : 1;
     const int nstride = nslots + 1;
     // neighbour indices: wave-uniform scalar loads for the 8 atom tiles, one per-lane load for the remainder tile; both are
-    // issued a whole slot before they are turned into addresses
+    // issued a whole entry before they are turned into addresses
     auto load_idx = [&](int s, int (&n)[GROUP], int& nr) {
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) n[t] = nbr5[(size_t)nstride * atom[t] + s];
@@ -236,47 +237,40 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     };
     const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB);
     auto frag_of = [&](int s, int si) { return reinterpret_cast<const char*>(fr_sig + (size_t)s * S5_FRAG_PER_SLOT + si * (5 * S5_FRAG_PER_RB)); };
+    auto spin_of = [&](int e) { return (e >> 8) ? 1 - sig : sig; };
     S5Slot cur;
     int nraw[GROUP], nrem;
-    int s_cur = share[1];
-    int s_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
-    load_idx(s_cur, nraw, nrem);
-    make_slot(nraw, nrem, cur, s_cur);
+    int e_cur = share[1];
+    int e_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
+    load_idx(e_cur & 255, nraw, nrem);
+    make_slot(nraw, nrem, cur, e_cur & 255);
     S5Pair X, Y;
     S5Single Z;
-    const int si0 = PAT == 0 ? 0 : sig;
-    s5_load_pair<0, false>(X, cur, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
-    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * si0, frag_of(s_cur, si0), lane_main, lane_rem, lane16);
+    s5_load_pair<0, false>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
     for (int j = 0; j < nmine; ++j) {
-        const int s_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last slot prefetches the first again (discarded)
-        load_idx(s_nxt, nraw, nrem);
+        const int e_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last entry prefetches the first again (discarded)
+        load_idx(e_nxt & 255, nraw, nrem);
         // (pinning the 32-bit lane offsets inside the loop makes hipcc emit SGPR-base + VGPR-offset loads, but costs 10 more VGPRs
         //  -> scratch spills in the group prologue and a 3.5 % slower kernel; measured, not used)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const int si = PAT == 0 ? hh : sig;
-            const unsigned so = 2592u * si;
-            const char* __restrict__ fb = frag_of(s_cur, si);
-            s5_load_pair<1>(Y, cur, so, fb, lane_main, lane_rem, lane16);
-            s5_mfma_pair(acc, X);
-            s5_interleave<14, 90>();
-            __builtin_amdgcn_sched_barrier(0);
-            s5_load_single(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
-            s5_mfma_pair(acc, Y);
-            s5_interleave<14, 90>();
-            __builtin_amdgcn_sched_barrier(0);
-            if (hh == NH - 1) {
-                make_slot(nraw, nrem, cur, s_nxt);        // the current slot's operands are all in flight or consumed: reuse its state
-                s5_load_pair<0>(X, cur, 2592u * si0, frag_of(s_nxt, si0), lane_main, lane_rem, lane16);
-            } else {
-                s5_load_pair<0>(X, cur, 2592u, frag_of(s_cur, 1), lane_main, lane_rem, lane16);
-            }
-            s5_mfma_single(acc, Z);
-            s5_interleave<14, 45>();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        s_cur = s_nxt;
-        s_nxt = s_nxt2;
+        const int si = spin_of(e_cur);
+        const unsigned so = 2592u * si;
+        const char* __restrict__ fb = frag_of(e_cur & 255, si);
+        s5_load_pair<1>(Y, cur, so, fb, lane_main, lane_rem, lane16);
+        s5_mfma_pair(acc, X);
+        s5_interleave<14, 90>();
+        __builtin_amdgcn_sched_barrier(0);
+        s5_load_single(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
+        s5_mfma_pair(acc, Y);
+        s5_interleave<14, 90>();
+        __builtin_amdgcn_sched_barrier(0);
+        make_slot(nraw, nrem, cur, e_nxt & 255);        // the current entry's operands are all in flight or consumed: reuse its state
+        s5_load_pair<0>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
+        s5_mfma_single(acc, Z);
+        s5_interleave<14, 45>();
+        __builtin_amdgcn_sched_barrier(0);
+        e_cur = e_nxt;
+        e_nxt = e_nxt2;
     }
 }
 
@@ -340,9 +334,7 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
 
-        s5_run_slots<0, TWO>(acc, M, fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
-        s5_run_slots<1, TWO>(acc, M + (1 + S4_MAXSLOTS), fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single,
-                             lane16, lane8);
+        s5_run_slots<TWO>(acc, M, fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
         // D layout: row w = 4 rb + l4 of spin sig (w = 18, 19: padding, exact zeros, not stored), column l15
         if (!OUT_KP) {

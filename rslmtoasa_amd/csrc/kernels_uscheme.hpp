@@ -111,57 +111,58 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     GramAcc Gm;
     Gm.zero();
     GroupWalk w(ngroups, wave);
-    U3Operands ot, oc, op;
-    if (w.g < w.end) {
-        const RowRef ra = group_row(order + (size_t)w.g * GROUP, l15, zero_block);
-        u3_load(ot, tv, ra.off, l4); u3_load(oc, uc, ra.off, l4); u3_load(op, up, ra.off, l4);
-    }
-    for (; w.g < w.end; w.g += w.step) {
-        const int* grp = order + (size_t)w.g * GROUP;
+    // row tiles of this wave, flattened: tile it = (group w.g + (it / 9) * step, rows 16 (it % 9) .. +15).  The operands of
+    // tiles it + 1 and it + 2 are in flight while tile it is multiplied (one 512-register wave per SIMD: the reads in
+    // flight are what hides the HBM latency, ~27 KB per wave)
+    const int ntile = (w.g < w.end) ? ((w.end - w.g + w.step - 1) / w.step) * 9 : 0;
+    auto load_tile = [&](int it, U3Operands& a, U3Operands& c, U3Operands& p) {
+        it = min(it, ntile - 1);
+        const int g = w.g + (it / 9) * w.step;
+        const RowRef ra = group_row(order + (size_t)g * GROUP, 16 * (it % 9) + l15, zero_block);
+        u3_load(a, tv, ra.off, l4); u3_load(c, uc, ra.off, l4); u3_load(p, up, ra.off, l4);
+    };
+    U3Operands ot, oc, op, nt, nc, np;
+    if (ntile > 0) { load_tile(0, ot, oc, op); load_tile(1, nt, nc, np); }
 #pragma unroll 1
-        for (int mt = 0; mt < 9; ++mt) {
-            // operands of the next row tile (next group after the last tile; re-reads the current tile at the very end)
-            U3Operands nt, nc, np;
-            {
-                const bool last = (mt == 8);
-                const int gn = last ? ((w.g + w.step < w.end) ? w.g + w.step : w.g) : w.g;
-                const RowRef rn = group_row(order + (size_t)gn * GROUP, last ? l15 : 16 * (mt + 1) + l15, zero_block);
-                u3_load(nt, tv, rn.off, l4); u3_load(nc, uc, rn.off, l4); u3_load(np, up, rn.off, l4);
-            }
-            double4_t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
-            double cr = 0.0;
-            u3_mac(ca, cb, cr, ot, T1);
-            u3_mac(ca, cb, cr, op, T2);
-            u3_mac(ca, cb, cr, oc, T3);
+    for (int it = 0; it < ntile; ++it) {
+        const int* grp = order + (size_t)(w.g + (it / 9) * w.step) * GROUP;
+        const int mt = it % 9;
+        U3Operands ft, fc, fp;
+        load_tile(it + 2, ft, fc, fp);
+        double4_t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+        double cr = 0.0;
+        u3_mac(ca, cb, cr, ot, T1);
+        u3_mac(ca, cb, cr, op, T2);
+        u3_mac(ca, cb, cr, oc, T3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
-                if (rs.valid) {
-                    up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j];
-                    if (KP) {
-                        const unsigned blk = (rs.off / BLD) * BLD, e0 = rs.off - blk;      // block base, 36 r
-                        uk[blk + kpt[e0 + l15]] = ca[j]; uk[blk + kpt[e0 + 16 + l15]] = cb[j];
-                    }
+        for (int j = 0; j < 4; ++j) {
+            const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
+            if (rs.valid) {
+                up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j];
+                if (KP) {
+                    const unsigned blk = (rs.off / BLD) * BLD, e0 = rs.off - blk;      // block base, 36 r
+                    uk[blk + kpt[e0 + l15]] = ca[j]; uk[blk + kpt[e0 + 16 + l15]] = cb[j];
                 }
             }
-            const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
-            if (rr.valid) {
-                up[rr.off + 32 + l3] = cr;
-                if (KP) { const unsigned blk = (rr.off / BLD) * BLD; uk[blk + kpt[rr.off - blk + 32 + l3]] = cr; }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double f0 = ca[j], f1 = cb[j];
-                const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);
-                Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
-                Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
-                Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
-                Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
-                Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
-                Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
-            }
-            ot = nt; oc = nc; op = np;
         }
+        const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
+        if (rr.valid) {
+            up[rr.off + 32 + l3] = cr;
+            if (KP) { const unsigned blk = (rr.off / BLD) * BLD; uk[blk + kpt[rr.off - blk + 32 + l3]] = cr; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double f0 = ca[j], f1 = cb[j];
+            const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);
+            Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
+            Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
+            Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
+            Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
+            Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
+            Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
+        }
+        ot = nt; oc = nc; op = np;
+        nt = ft; nc = fc; np = fp;
     }
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }
