@@ -39,6 +39,10 @@ program dump_fixture
    type(hamiltonian), target :: hamiltonian_obj
    type(recursion), target :: recursion_obj
    type(mix), target :: mix_obj
+   type(dos), target :: dos_obj
+   type(green), target :: green_obj
+   real(rp), allocatable :: a_inf(:, :, :), b_inf(:, :, :), a_inf0(:), b_inf0(:)
+   integer :: nw, nen, sym_i
    integer :: ia, u, kind_rec, nslots, hoh_i, nsites, ncheb
    real(rp) :: acheb, bcheb
    character(len=32) :: pre
@@ -149,6 +153,25 @@ program dump_fixture
    case (0)
       write (u) recursion_obj%a_b
       write (u) recursion_obj%b2_b
+      ! ---- the stage right after the recursion (self.f90:820-831, run_dos): zsqr, then green%block_green; appended so
+      !      that the Green-function kernel (SURVEY 8f1) can be pinned: energies, terminator, sqrt(B^2), g0
+      dos_obj = dos(recursion_obj, energy_obj)
+      green_obj = green(dos_obj)
+      call energy_obj%e_mesh()
+      call recursion_obj%zsqr()
+      nen = energy_obj%channels_ldos + 10
+      allocate (a_inf(18, 18, lattice_obj%nrec), b_inf(18, 18, lattice_obj%nrec), a_inf0(lattice_obj%nrec), b_inf0(lattice_obj%nrec))
+      nw = 10*control_obj%lld
+      call recursion_obj%get_terminf(recursion_obj%a_b, recursion_obj%b2_b, atoms_per_process, control_obj%lld, 18, nw, a_inf, b_inf, a_inf0, b_inf0)
+      call green_obj%block_green()
+      sym_i = 0
+      if (control_obj%sym_term) sym_i = 1
+      write (u) int(z'47524e31'), nen, sym_i
+      write (u) energy_obj%ene(1:nen)
+      write (u) a_inf
+      write (u) b_inf
+      write (u) recursion_obj%b2_b
+      write (u) green_obj%g0(:, :, 1:nen, 1:lattice_obj%nrec)
    case (1)
       write (u) recursion_obj%mu_n
    case (2)

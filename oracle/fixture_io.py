@@ -15,6 +15,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x52534658
+GREEN_MAGIC = 0x47524e31
 KIND_BLOCK, KIND_CHEB, KIND_SCALAR, KIND_BLOCK_IJ, KIND_CHEB_IJ = 0, 1, 2, 3, 4
 
 
@@ -49,7 +50,16 @@ def read_fixture_bin(path):
             d["hall"] = _rd(f, np.complex128, (18, 18, nslots, nmax))
             d["hallo"] = _rd(f, np.complex128, (18, 18, nslots, nmax))
         _read_outputs(f, d, kind, lld, nrec, llmax)
-        assert f.read(1) == b"", "trailing bytes in fixture"
+        tail = f.read(12)
+        if tail:
+            # Green-function stage appended by dump_fixture.f90 for block recursions (self.f90:820-831 run_dos):
+            # energies, terminator, sqrt(B^2) (zsqr), g0 = block_green (green.f90:588-621, bgreen :1191-1339)
+            gmagic, nen, sym = struct.unpack("<iii", tail)
+            assert gmagic == GREEN_MAGIC
+            d["green"] = dict(nen=nen, sym_term=sym, ene=_rd(f, np.float64, (nen,)), a_inf=_rd(f, np.float64, (18, 18, nrec)),
+                              b_inf=_rd(f, np.float64, (18, 18, nrec)), b_sqrt=_rd(f, np.complex128, (18, 18, lld, nrec)),
+                              g0=_rd(f, np.complex128, (18, 18, nen, nrec)))
+            assert f.read(1) == b"", "trailing bytes in fixture"
     return d
 
 
@@ -104,7 +114,7 @@ OUTPUT_KEYS = ("a_b", "b2_b", "mu_n", "a", "b2")
 
 
 def save_golden(path, d, extra=None, drop=("cr",)):
-    out = {k: np.asarray(v) for k, v in d.items() if k not in drop and k != "nncols" and k != "llmax"}
+    out = {k: np.asarray(v) for k, v in d.items() if k not in drop and k != "nncols" and k != "llmax" and k != "green"}
     if not d.get("hoh"):
         # eeo/enim are not read by the non-hoh path: do not store megabytes of unused blocks
         out.pop("eeo", None); out.pop("enim", None); out.pop("hallo", None)

@@ -105,6 +105,44 @@ def run_case(name):
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
+GREEN_STRIDE = 40          # every 40th energy of the reference's mesh (channels_ldos + 10 points) is kept
+
+
+def run_green_case(name):
+    """<name>_green.npz: inputs and the reference's output of green%block_green for the same run as <name>.npz:
+    a_b (reference coefficients), sqrt(B^2) after zsqr, the terminator (get_terminf), the energy mesh and g0 on a
+    sub-sampled set of energies (every energy is an independent continued fraction, green.f90:1257-1336)."""
+    case_dir, patch = CASES[name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_gx_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        p = os.path.join(scratch, "input.nml")
+        txt = patch_namelist(open(p).read(), patch)
+        open(p, "w").write(txt)
+        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_fixture.x")
+        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_fixture failed for " + name)
+        d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
+        g = d["green"]
+        idx = np.arange(0, g["nen"], GREEN_STRIDE, dtype=np.int32)
+        out = dict(lld=d["lld"], nrec=d["nrec"], nen_full=g["nen"], sym_term=g["sym_term"], ene_idx=idx, ene=g["ene"][idx],
+                   ene_full_first=g["ene"][0], ene_full_step=g["ene"][1] - g["ene"][0],
+                   a_inf=g["a_inf"], b_inf=g["b_inf"], a_b=d["a_b"], b_sqrt=g["b_sqrt"], g0=g["g0"][:, :, idx, :],
+                   source_case=np.array(case_dir), namelist_patch=np.array(repr(patch)))
+        path = os.path.join(GOLD, name + "_green.npz")
+        np.savez_compressed(path, **out)
+        print("%-24s green: nen=%d kept=%d nrec=%d lld=%d sym_term=%d -> %.1f KB" % (name, g["nen"], len(idx), d["nrec"], d["lld"], g["sym_term"],
+                                                                                   os.path.getsize(path) / 1024))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def slot_vectors(d):
     """Displacement vector (units of alat) of every neighbour slot, from an interior atom
     (slot m is the same displacement for every atom of a type: lattice.f90:2823-2893)."""
@@ -169,9 +207,11 @@ SUPERCELLS = {
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS))
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES])
     for n in want:
-        if n in CASES:
+        if n.endswith("_green"):
+            run_green_case(n[:-len("_green")])
+        elif n in CASES:
             run_case(n)
         else:
             supercell_case(n, **SUPERCELLS[n])

@@ -124,6 +124,22 @@ def zsqr(b2_b):
     return out
 
 
+def block_green(a_b, b_sqrt, ene, a_inf, b_inf, eta=0.0 + 0.0j, sym_term=False):
+    """green%bgreen (green.f90:1191) for ONE site: a_b, b_sqrt (18,18,lld) -> g0 (18,18,len(ene))."""
+    a_b = np.asfortranarray(a_b, dtype=np.complex128); b_sqrt = np.asfortranarray(b_sqrt, dtype=np.complex128)
+    ene = np.ascontiguousarray(ene, dtype=np.float64)
+    a_inf = np.asfortranarray(a_inf, dtype=np.float64); b_inf = np.asfortranarray(b_inf, dtype=np.float64)
+    g0 = np.zeros((18, 18, len(ene)), dtype=np.complex128, order="F")
+    L = lib()
+    L.orc_block_green.restype = C.c_int
+    L.orc_block_green.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 5
+    rc = L.orc_block_green(a_b.shape[2], len(ene), ene.ctypes.data_as(C.c_void_p), float(np.real(eta)), float(np.imag(eta)), int(bool(sym_term)),
+                           a_inf.ctypes.data_as(C.c_void_p), b_inf.ctypes.data_as(C.c_void_p), a_b.ctypes.data_as(C.c_void_p),
+                           b_sqrt.ctypes.data_as(C.c_void_p), g0.ctypes.data_as(C.c_void_p))
+    assert rc == 0, "singular matrix in the continued fraction"
+    return g0
+
+
 def site_partition(rank, nprocs, nsites):
     s, e = C.c_int(), C.c_int()
     lib().orc_site_partition(rank, nprocs, nsites, C.byref(s), C.byref(e))
