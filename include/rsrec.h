@@ -89,6 +89,19 @@ int rsrec_block_lanczos_seeded(rsrec_t *h, int nchains, int nseed, const int32_t
  * Replaces zsqr (recursion.f90:1980-2023). */
 int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);
 
+/* Green function from the block coefficients -- the stage right after the recursion.
+ * Replaces green%block_green (green.f90:588-621) + green%bgreen (:1191-1339) for the sites of this rank:
+ *   g0(:,:,ie,site) = B_1^H [ E - A_1 - B_2^H [ ... ]^-1 B_2 ]^-1 B_1 , levels lld-1 .. 1, closed by the square-root terminator.
+ *   ene    : real (nen) energy mesh, energy%ene(1:channels_ldos+10) (energy.f90:205-207)
+ *   eta    : complex broadening added to E on the diagonal (block_green: 0; block_green_eta: the caller's eta)
+ *   sym_term: control%sym_term (orbital-independent terminator, green.f90:1268-1277)
+ *   a_inf, b_inf : real (18,18,nsites) from recursion%get_terminf (recursion.f90:2092; stays on the CPU)
+ *   a_b    : complex (18,18,lld,nsites) as returned by rsrec_block_lanczos
+ *   b_sqrt : complex (18,18,lld,nsites) = b2_b AFTER rsrec_zsqr (self.f90:829 calls zsqr before block_green)
+ *   g0     : complex (18,18,nen,nsites) out */
+int rsrec_block_green(rsrec_t *h, int nsites, int lld, int nen, const double *ene, double eta_re, double eta_im, int sym_term,
+                      const double *a_inf, const double *b_inf, const double *a_b, const double *b_sqrt, double *g0);
+
 /* Chebyshev (KPM, moment doubling) recursion.  Replaces chebyshev_recur (recursion.f90:3057-3130) with
  * cheb_0th_mom (:2145), cheb_1st_mom[_hoh] (:2169/:2245), chebyshev_recur_ll[_hoh] (:2495/:2605).
  *   a, b : scale and shift, a = (energy_max-energy_min)/(2-0.3), b = (energy_max+energy_min)/2 (:3078-3079)

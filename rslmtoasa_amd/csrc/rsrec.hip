@@ -27,6 +27,7 @@
 #include "kernels_spmm4.hpp"
 #include "kernels_spmm5.hpp"
 #include "kernels_uscheme.hpp"
+#include "kernels_green.hpp"
 
 using namespace rsrec;
 
@@ -68,6 +69,7 @@ struct rsrec_handle {
     Spmm5Operator s5_op;
     int s5_built = 0;
     // work
+    DevBuf d_green_in, d_green_out;   // rsrec_block_green
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
@@ -235,7 +237,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+    DevBuf* all[] = {&h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
@@ -875,6 +877,50 @@ extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
     HIPCK(h, hipMemcpyAsync(&status, h->d_status.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
+    return RSREC_OK;
+}
+
+// green%block_green / bgreen (green.f90:588-621, :1191-1339): g0(:,:,:,site) from the block coefficients of every site.
+extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const double* ene, double eta_re, double eta_im, int sym_term,
+                                 const double* a_inf, const double* b_inf, const double* a_b, const double* b_sqrt, double* g0) {
+    if (!h) return RSREC_ERR_ARG;
+    if (nsites < 0 || lld < 1 || nen < 0 || (nsites > 0 && nen > 0 && (!ene || !a_inf || !b_inf || !a_b || !b_sqrt || !g0)))
+        return fail(h, RSREC_ERR_ARG, "rsrec_block_green: bad argument");
+    if (nsites == 0 || nen == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t cbytes = (size_t)lld * BLK * sizeof(double2);       // coefficients of one site (each of a_b, b_sqrt)
+    const size_t tbytes = (size_t)BLK * sizeof(double);              // terminator of one site (each of a_inf, b_inf)
+    const size_t gbytes = (size_t)nen * BLK * sizeof(double2);       // g0 of one site
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)1 << 30) / gbytes));   // <= 1 GiB of g0 on the device at a time
+    HIPCK(h, h->d_green_in.reserve((size_t)chunk * (2 * cbytes + 2 * tbytes) + (size_t)nen * sizeof(double)));
+    HIPCK(h, h->d_green_out.reserve((size_t)chunk * gbytes));
+    char* base = static_cast<char*>(h->d_green_in.p);
+    double* d_ene = reinterpret_cast<double*>(base);
+    double2* d_ab = reinterpret_cast<double2*>(base + (size_t)nen * sizeof(double));
+    double2* d_bs = reinterpret_cast<double2*>(reinterpret_cast<char*>(d_ab) + (size_t)chunk * cbytes);
+    double* d_ai = reinterpret_cast<double*>(reinterpret_cast<char*>(d_bs) + (size_t)chunk * cbytes);
+    double* d_bi = reinterpret_cast<double*>(reinterpret_cast<char*>(d_ai) + (size_t)chunk * tbytes);
+    HIPCK(h, hipMemcpyAsync(d_ene, ene, (size_t)nen * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    reset_timing(h);
+    hipEvent_t ev0 = next_event(h);
+    for (int s0 = 0; s0 < nsites; s0 += chunk) {
+        const int ns = std::min(chunk, nsites - s0);
+        HIPCK(h, hipMemcpyAsync(d_ab, a_b + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(d_bs, b_sqrt + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(d_ai, a_inf + (size_t)s0 * BLK, (size_t)ns * tbytes, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(d_bi, b_inf + (size_t)s0 * BLK, (size_t)ns * tbytes, hipMemcpyHostToDevice, h->stream));
+        const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, ns);
+        hipEvent_t k0 = next_event(h);
+        k_block_green<<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai, d_bi, d_ab, d_bs, h->d_green_out.as<double2>());
+        hipEvent_t k1 = next_event(h);
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipMemcpyAsync(g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->t_hop_ms += ev_ms(k0, k1);          // reported as "hop_ms": the Green kernel itself; total_ms includes the transfers
+    }
+    hipEvent_t ev1 = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(ev0, ev1);
     return RSREC_OK;
 }
 

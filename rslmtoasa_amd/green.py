@@ -1,0 +1,42 @@
+"""Host-side mirror of the reference's ``green`` type for the block-recursion Green function (green.f90:42-72, :588-621, :1191-1339).
+
+Only the stage that sits directly on the recursion's output is here: ``block_green`` turns the block coefficients of the
+sites this rank owns into ``g0(18,18,nE,site)`` on the GPU (``rsrec_block_green``).  The terminator ``a_inf, b_inf`` comes
+from ``recursion%get_terminf`` (recursion.f90:2092), which stays on the CPU in the reference's own code and
+is therefore an argument here.
+"""
+import numpy as np
+
+
+def _ptr(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Green:
+    def __init__(self, recursion, ene, sym_term=False):
+        self.recursion = recursion
+        self.ene = np.ascontiguousarray(ene, dtype=np.float64)      # energy%ene(1:channels_ldos+10), energy.f90:205-207
+        self.sym_term = bool(sym_term)                              # control%sym_term
+        self.g0 = None
+
+    def block_green(self, a_inf, b_inf, eta=0.0 + 0.0j, nsites=None):
+        """green%block_green: requires ``recursion.zsqr()`` to have been called (self.f90:829), like the reference."""
+        rec = self.recursion
+        n = rec.a_b.shape[3] if nsites is None else nsites
+        lld = rec.a_b.shape[2]
+        a_b = np.asfortranarray(rec.a_b[:, :, :, :n])
+        b_s = np.asfortranarray(rec.b2_b[:, :, :, :n])
+        a_inf = np.asfortranarray(a_inf, dtype=np.float64)
+        b_inf = np.asfortranarray(b_inf, dtype=np.float64)
+        assert a_inf.shape == (18, 18, n) and b_inf.shape == (18, 18, n)
+        g0 = np.zeros((18, 18, len(self.ene), n), dtype=np.complex128, order="F")
+        rec._check(rec._L.rsrec_block_green(rec._h, n, lld, len(self.ene), _ptr(self.ene), float(np.real(eta)), float(np.imag(eta)),
+                                            int(self.sym_term), _ptr(a_inf), _ptr(b_inf), _ptr(a_b), _ptr(b_s), _ptr(g0)))
+        self.g0 = g0
+        return g0
+
+    def ldos(self):
+        """Orbital-resolved local density of states, -Im g0_jj / pi (density_of_states.f90:248-260)."""
+        d = np.arange(18)
+        return -self.g0[d, d].imag / np.pi

@@ -1,0 +1,87 @@
+"""Green-function stage on the GPU: rsrec_block_green against the reference's g0 and against the CPU oracle.
+
+The fixtures hold, for the same reference runs as the recursion fixtures, the inputs of green%block_green (coefficients,
+sqrt(B^2), terminator, energies) and its output g0 on every 40th energy of the reference's 2510-point mesh
+(oracle/make_fixtures.py run_green_case).  Bar: 1e-10 relative per energy (every energy is an independent 18x18 continued
+fraction; the bound is on max|g - g_ref| / max|g_ref| over the 18x18 block)."""
+import numpy as np
+import pytest
+
+from helpers import GOLD as GOLDEN_DIR, RTOL, load_golden, objects_from, problem_dict, rel_err
+from rslmtoasa_amd.green import Green
+from rslmtoasa_amd.recursion import Recursion
+
+pytestmark = pytest.mark.gpu
+
+GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
+
+
+def load_green(name):
+    import os
+    with np.load(os.path.join(GOLDEN_DIR, name + "_green.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def per_energy_err(g, ref):
+    return max(np.abs(g[:, :, k] - ref[:, :, k]).max() / np.abs(ref[:, :, k]).max() for k in range(ref.shape[2]))
+
+
+@pytest.mark.parametrize("name", GREEN_CASES)
+def test_block_green_from_reference_coefficients(name, oracle_lib):
+    """Isolates the Green kernel: reference coefficients in, reference g0 out."""
+    z = load_green(name)
+    g = load_golden(name)
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
+    n = int(z["nrec"])
+    rec.a_b[:, :, :, :n] = z["a_b"]
+    rec.b2_b[:, :, :, :n] = z["b_sqrt"]
+    gr = Green(rec, z["ene"], sym_term=bool(z["sym_term"]))
+    g0 = gr.block_green(z["a_inf"], z["b_inf"])
+    for s in range(n):
+        assert per_energy_err(g0[:, :, :, s], z["g0"][:, :, :, s]) < RTOL
+        o = oracle_lib.block_green(z["a_b"][:, :, :, s], z["b_sqrt"][:, :, :, s], z["ene"], z["a_inf"][:, :, s], z["b_inf"][:, :, s],
+                                   sym_term=bool(z["sym_term"]))
+        assert per_energy_err(g0[:, :, :, s], o) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("name", GREEN_CASES)
+def test_recursion_zsqr_green_pipeline(name):
+    """GPU recursion -> GPU zsqr -> GPU Green function, against the reference's g0 (terminator from the reference run:
+    get_terminf stays on the CPU in the reference too).  LDOS = -Im g_jj / pi must be non-negative."""
+    z = load_green(name)
+    g = load_golden(name)
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
+    rec.recur_b()
+    rec.zsqr()
+    n = int(z["nrec"])
+    assert rel_err(rec.b2_b[:, :, :, :n], z["b_sqrt"]) < RTOL
+    gr = Green(rec, z["ene"], sym_term=bool(z["sym_term"]))
+    g0 = gr.block_green(z["a_inf"], z["b_inf"], nsites=n)
+    for s in range(n):
+        assert per_energy_err(g0[:, :, :, s], z["g0"][:, :, :, s]) < 1e-9     # coefficients carry ~1e-14, amplified by the inversions near band edges
+    assert gr.ldos().min() > -1e-9
+    rec.close()
+
+
+def test_block_green_properties_full_mesh():
+    """Full 2510-point mesh, many sites: eta > 0 makes g analytic -> -Im g_jj > 0 everywhere; identical sites give identical g."""
+    z = load_green("bccFe_nsp2_block")
+    g = load_golden("bccFe_nsp2_block")
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
+    nrep = 8
+    rec.a_b = np.asfortranarray(np.repeat(z["a_b"][:, :, :, :1], nrep, axis=3))
+    rec.b2_b = np.asfortranarray(np.repeat(z["b_sqrt"][:, :, :, :1], nrep, axis=3))
+    ene = float(z["ene_full_first"]) + float(z["ene_full_step"]) * np.arange(int(z["nen_full"]))
+    gr = Green(rec, ene)
+    a_inf = np.repeat(z["a_inf"][:, :, :1], nrep, axis=2)
+    b_inf = np.repeat(z["b_inf"][:, :, :1], nrep, axis=2)
+    g0 = gr.block_green(a_inf, b_inf, eta=0.005j)
+    assert np.isfinite(g0).all()
+    assert gr.ldos().min() > 0.0
+    for s in range(1, nrep):
+        assert np.array_equal(g0[:, :, :, s], g0[:, :, :, 0])
+    # the sub-sampled energies of the fixture are reproduced by the full-mesh run at eta = 0
+    g00 = gr.block_green(a_inf, b_inf)
+    assert per_energy_err(g00[:, :, z["ene_idx"], 0], z["g0"][:, :, :, 0]) < RTOL
+    rec.close()
