@@ -1,0 +1,93 @@
+!------------------------------------------------------------------------------
+! RS-LMTO-ASA drop-in, second stage: the Green function of the block recursion on the GPU.
+!------------------------------------------------------------------------------
+!
+! MODULE: green_gpu_mod
+!
+! DESCRIPTION:
+!> `type, extends(green) :: green_gpu` overrides ONE procedure of the reference's `green` type: `bgreen`
+!> (green.f90:1191-1339), the continued fraction  coefficients -> g(E)  that `block_green` (:588), `block_green_eta`
+!> (:541) and the inter-site variants call per site.  Everything else -- the terminator (`recursion%get_terminf`, CPU),
+!> the result arrays `g0, gij, ...`, `sgreen`, `chebyshev_green` -- is inherited.  The GPU side is `rsrec_block_green`
+!> (include/rsrec.h): one wave per energy point, 18x18 complex inverse with LAPACK's pivot rule, in LDS.
+!>
+!> `bands`, `self` and `exchange` hold `class(green), pointer` (bands.f90:49, self.f90:76, exchange.f90:48); the only
+!> non-polymorphic spot is the dummy of the `bands` constructor (bands.f90:121, `type(green), target`), which a maintainer
+!> changes to `class(green), target` (INTEGRATION.md).
+!------------------------------------------------------------------------------
+module green_gpu_mod
+   use, intrinsic :: iso_c_binding
+   use green_mod
+   use density_of_states_mod, only: dos
+   use precision_mod, only: rp
+   use logger_mod, only: g_logger
+   use timer_mod, only: g_timer
+   use rsrec_binding
+   use recursion_gpu_mod, only: rsrec_gpu_context
+   implicit none
+
+   private
+
+   type, public, extends(green) :: green_gpu
+   contains
+      procedure :: bgreen => gpu_bgreen
+   end type green_gpu
+
+   interface green_gpu
+      procedure :: gpu_constructor
+   end interface green_gpu
+
+contains
+
+   !> Same construction as green.f90:101-113.
+   function gpu_constructor(dos_obj) result(obj)
+      type(green_gpu) :: obj
+      type(dos), target, intent(in) :: dos_obj
+
+      obj%dos => dos_obj
+      obj%recursion => dos_obj%recursion
+      obj%en => dos_obj%en
+      obj%symbolic_atom => dos_obj%recursion%hamiltonian%charge%lattice%symbolic_atoms
+      obj%lattice => dos_obj%recursion%lattice
+      obj%control => dos_obj%recursion%lattice%control
+      call obj%restore_to_default()
+   end function gpu_constructor
+
+   !> Replaces green.f90:1191-1339 (same interface; `g_out` is zeroed and the energy range ie_start .. ie_start+ie_len-1 filled).
+   subroutine gpu_bgreen(this, g_out, i_site, ie_start, ie_len, a_inf, b_inf, eta)
+      class(green_gpu), intent(inout) :: this
+      integer, intent(in) :: i_site
+      integer, intent(in) :: ie_start
+      integer, intent(in) :: ie_len
+      complex(rp), dimension(18, 18, this%en%channels_ldos + 10), intent(inout) :: g_out
+      real(rp), dimension(18, 18), intent(in) :: a_inf
+      real(rp), dimension(18, 18), intent(in) :: b_inf
+      complex(rp), intent(in) :: eta
+      !
+      integer :: ll
+      integer(c_int) :: rc, sym_i
+      type(c_ptr) :: handle
+      real(rp), allocatable, target :: ene(:), ai(:, :), bi(:, :)
+      complex(rp), allocatable, target :: ab(:, :, :), bs(:, :, :), gt(:, :, :)
+
+      g_out = (0.0d0, 0.0d0)
+      if (ie_len <= 0) return
+      ll = this%control%lld
+      allocate (ene(ie_len), ai(18, 18), bi(18, 18), ab(18, 18, ll), bs(18, 18, ll), gt(18, 18, ie_len))
+      ene = this%en%ene(ie_start:ie_start + ie_len - 1)
+      ai = a_inf
+      bi = b_inf
+      ab = this%recursion%a_b(:, :, 1:ll, i_site)
+      bs = this%recursion%b2_b(:, :, 1:ll, i_site)          ! sqrt(B^2): zsqr ran before (self.f90:829)
+      sym_i = 0
+      if (this%control%sym_term) sym_i = 1
+      handle = rsrec_gpu_context()
+      call g_timer%start('bgreen-gpu')
+      rc = rsrec_block_green(handle, 1_c_int, int(ll, c_int), int(ie_len, c_int), c_loc(ene), real(eta, c_double), aimag(eta), sym_i, &
+                             c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), c_loc(gt))
+      call g_timer%stop('bgreen-gpu')
+      if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
+      g_out(:, :, ie_start:ie_start + ie_len - 1) = gt
+   end subroutine gpu_bgreen
+
+end module green_gpu_mod

@@ -49,7 +49,7 @@ module recursion_gpu_mod
       procedure :: gpu_constructor
    end interface recursion_gpu
 
-   public :: rsrec_gpu_shutdown
+   public :: rsrec_gpu_shutdown, rsrec_gpu_context
 
    !> the per-process device context (lazy)
    type(c_ptr), save :: g_handle = c_null_ptr
@@ -68,6 +68,19 @@ contains
       obj%control => hamiltonian_obj%charge%lattice%control
       call obj%restore_to_default()
    end function gpu_constructor
+
+   !> The per-process device context, created on first use (shared with green_gpu_mod).
+   function rsrec_gpu_context() result(handle)
+      type(c_ptr) :: handle
+      integer(c_int) :: rc, ndev
+      if (.not. c_associated(g_handle)) then
+         ndev = rsrec_device_count()
+         if (ndev <= 0) call g_logger%fatal('recursion_gpu: no usable GPU (librsrec has no CPU fallback)', __FILE__, __LINE__)
+         rc = rsrec_create(g_handle, int(mod(rank, ndev), c_int))
+         if (rc /= 0) call g_logger%fatal('recursion_gpu: rsrec_create failed', __FILE__, __LINE__)
+      end if
+      handle = g_handle
+   end function rsrec_gpu_context
 
    subroutine check(rc, where)
       integer(c_int), intent(in) :: rc

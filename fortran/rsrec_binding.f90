@@ -43,6 +43,16 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_block_green(handle, nsites, lld, nen, ene, eta_re, eta_im, sym_term, a_inf, b_inf, a_b, b_sqrt, g0) &
+         bind(C, name='rsrec_block_green') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld, nen, sym_term
+         real(c_double), value :: eta_re, eta_im
+         type(c_ptr), value :: ene, a_inf, b_inf, a_b, b_sqrt, g0
+         integer(c_int) :: rc
+      end function
+
       function rsrec_set_positions(handle, cr) bind(C, name='rsrec_set_positions') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

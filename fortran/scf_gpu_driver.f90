@@ -21,6 +21,7 @@ program scf_gpu_driver
    use recursion_gpu_mod
    use density_of_states_mod
    use green_mod
+   use green_gpu_mod
    use bands_mod
    use self_mod
    use calculation_mod
@@ -36,7 +37,7 @@ program scf_gpu_driver
    type(charge), target :: charge_obj
    type(hamiltonian), target :: hamiltonian_obj
    type(recursion_gpu), target :: recursion_obj
-   type(green), target :: green_obj
+   type(green_gpu), target :: green_obj      ! <-- second drop-in: the Green function of the block recursion on the GPU
    type(dos), target :: dos_obj
    type(bands), target :: bands_obj
    type(mix), target :: mix_obj
@@ -90,8 +91,12 @@ program scf_gpu_driver
    hamiltonian_obj = hamiltonian(charge_obj)
    recursion_obj = recursion_gpu(hamiltonian_obj, energy_obj)     ! <-- the one-line change
    dos_obj = dos(recursion_obj, energy_obj)
-   green_obj = green(dos_obj)
-   bands_obj = bands(green_obj)
+   green_obj = green_gpu(dos_obj)
+   ! bands' constructor takes a non-polymorphic `type(green)` dummy (bands.f90:121); in the reference itself that dummy
+   ! becomes `class(green)` (INTEGRATION.md).  With the reference's object code as it is, the parent component is passed
+   ! and the class pointer re-pointed at the whole object, which is what the polymorphic dummy would have done.
+   bands_obj = bands(green_obj%green)
+   bands_obj%green => green_obj
    self_obj = self(bands_obj, mix_obj)
    call g_timer%start('self-consistency')
    call self_obj%run()

@@ -50,6 +50,10 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     assert "fatal" not in log.lower(), log[-3000:]                      # tests/run_test.py:119-131
+    if "'block'" in str(case["patch"]):
+        # block recursions: the Green function (green%bgreen) also ran on the GPU (fortran/green_gpu.f90); its timer region is
+        # listed in the reference's own timing report
+        assert "bgreen-gpu" in log, log[-3000:]
     at, rt = case["abs_tol"], case["rel_tol"]
     bad = []
     for fn, keys in case["expected"].get("nml", {}).items():
