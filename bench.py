@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--spmm4", type=int, default=-1, help="SpMM kernel: 0 = 16x16x4 MFMA, 1 = 4x4x4 MFMA one wave per group, 4 = 4x4x4 cooperative; -1 = library default")
     ap.add_argument("--no-positions", action="store_true", help="do not pass atom positions (locality hint)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-green", action="store_true", help="skip the (untimed, separately reported) Green-function stage")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -208,6 +209,27 @@ def main():
                          "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
                                       "note": "whole recursion level, algorithmic 51840 B per atom-step"}},
         }
+        if world == 1 and not args.no_green:
+            # Not part of `value`: the stage behind the recursion (zsqr + green%bgreen) for the same sites, once, so
+            # that "sites/s from Hamiltonian to g0" can be quoted.  Terminator (get_terminf, a CPU routine in the reference too)
+            # taken from the bulk bcc Fe fixture of the same Hamiltonian; 2510 energies = the reference's default mesh.
+            try:
+                from rslmtoasa_amd.green import Green
+                gz = np.load(os.path.join(ROOT, "tests", "golden", "bccFe_nsp2_block_green.npz"), allow_pickle=False)
+                nloc = args.sites
+                ene = float(gz["ene_full_first"]) + float(gz["ene_full_step"]) * np.arange(int(gz["nen_full"]))
+                a_inf = np.repeat(gz["a_inf"][:, :, :1], nloc, axis=2); b_inf = np.repeat(gz["b_inf"][:, :, :1], nloc, axis=2)
+                t0 = time.perf_counter()
+                rec.zsqr()
+                gr = Green(rec, ene)
+                gr.block_green(a_inf, b_inf, nsites=nloc)
+                tg = time.perf_counter() - t0
+                tmg = rec.timing()
+                out["green"] = {"wall_ms": tg * 1e3, "kernel_ms": tmg["hop_ms"], "energies": len(ene),
+                                "sites_per_s_recursion_plus_green": nloc / (elapsed / args.steps + tg),
+                                "note": "zsqr + rsrec_block_green (green.f90:1191 bgreen) for the sites of one step, incl. the g0 download; not in `value`"}
+            except Exception as e:  # noqa
+                print("green stage skipped: %r" % (e,), file=sys.stderr)
         if world == 1 and not args.no_cpu:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             out["cpu_baseline"] = cpu_baseline(nn, ee, lsham, args.lld, threads)
