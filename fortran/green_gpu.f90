@@ -31,6 +31,7 @@ module green_gpu_mod
    type, public, extends(green) :: green_gpu
    contains
       procedure :: bgreen => gpu_bgreen
+      procedure :: chebyshev_green => gpu_chebyshev_green
    end type green_gpu
 
    interface green_gpu
@@ -89,5 +90,46 @@ contains
       if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
       g_out(:, :, ie_start:ie_start + ie_len - 1) = gt
    end subroutine gpu_bgreen
+
+   !> Replaces green.f90:1030-1108: g0 of the sites of this rank from the Chebyshev moments.  The side effect of the reference
+   !> routine -- recursion%mu_ng = mu_n * Jackson kernel (* 2 beyond the first moment), read later by bands.f90:762 -- is kept.
+   subroutine gpu_chebyshev_green(this)
+      use mpi_mod, only: start_atom, end_atom, g2l_map
+      use math_mod, only: jackson_kernel
+      class(green_gpu), intent(inout) :: this
+      integer :: n, n_glob, nv, nm, l, m, nloc, n1
+      integer(c_int) :: rc
+      type(c_ptr) :: handle
+      real(rp), dimension(this%control%lld*2 + 2) :: kernel
+      real(rp), allocatable, target :: ene(:)
+      complex(rp), allocatable, target :: mu(:, :, :, :), gt(:, :, :, :)
+
+      this%g0 = 0.0d0
+      nv = this%en%channels_ldos + 10
+      nm = this%control%lld*2 + 2
+      nloc = end_atom - start_atom + 1
+      if (nloc <= 0) return
+      call jackson_kernel(nm, kernel)
+      do n_glob = start_atom, end_atom
+         n = g2l_map(n_glob)
+         do l = 1, 18
+            do m = 1, 18
+               this%recursion%mu_ng(l, m, :, n) = this%recursion%mu_n(l, m, :, n)*kernel(:)
+            end do
+         end do
+         this%recursion%mu_ng(:, :, 2:nm, n) = this%recursion%mu_ng(:, :, 2:nm, n)*2.0_rp
+      end do
+      n1 = g2l_map(start_atom)
+      allocate (ene(nv), mu(18, 18, nm, nloc), gt(18, 18, nv, nloc))
+      ene = this%en%ene(1:nv)
+      mu = this%recursion%mu_n(:, :, 1:nm, n1:n1 + nloc - 1)
+      handle = rsrec_gpu_context()
+      call g_timer%start('chebyshev-green-gpu')
+      rc = rsrec_chebyshev_green(handle, int(nloc, c_int), int(this%control%lld, c_int), int(nv, c_int), c_loc(ene), &
+                                 real(this%en%energy_min, c_double), real(this%en%energy_max, c_double), c_loc(mu), c_loc(gt))
+      call g_timer%stop('chebyshev-green-gpu')
+      if (rc /= 0) call g_logger%fatal('rsrec_chebyshev_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
+      this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
+   end subroutine gpu_chebyshev_green
 
 end module green_gpu_mod

@@ -53,6 +53,16 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_chebyshev_green(handle, nsites, lld, nen, ene, energy_min, energy_max, mu_n, g0) &
+         bind(C, name='rsrec_chebyshev_green') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld, nen
+         real(c_double), value :: energy_min, energy_max
+         type(c_ptr), value :: ene, mu_n, g0
+         integer(c_int) :: rc
+      end function
+
       function rsrec_set_positions(handle, cr) bind(C, name='rsrec_set_positions') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

@@ -102,6 +102,13 @@ int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);
 int rsrec_block_green(rsrec_t *h, int nsites, int lld, int nen, const double *ene, double eta_re, double eta_im, int sym_term,
                       const double *a_inf, const double *b_inf, const double *a_b, const double *b_sqrt, double *g0);
 
+/* Green function from the Chebyshev moments.  Replaces green%chebyshev_green (green.f90:1030-1108) for the sites of this rank:
+ *   g0(:,:,ie,site) = sum_i mu_n(:,:,i,site) k_i (-i) exp(-i (i-1) acos w_ie) / sqrt(a^2 - (e_ie - b)^2),  w = (e - b)/a,
+ *   k = Jackson kernel (math.f90:1641) times 2 for i > 1; a, b from energy_min/max as in rsrec_chebyshev.
+ *   mu_n : complex (18,18,2*lld+2,nsites) as returned by rsrec_chebyshev;  g0 : complex (18,18,nen,nsites) out */
+int rsrec_chebyshev_green(rsrec_t *h, int nsites, int lld, int nen, const double *ene, double energy_min, double energy_max,
+                          const double *mu_n, double *g0);
+
 /* Chebyshev (KPM, moment doubling) recursion.  Replaces chebyshev_recur (recursion.f90:3057-3130) with
  * cheb_0th_mom (:2145), cheb_1st_mom[_hoh] (:2169/:2245), chebyshev_recur_ll[_hoh] (:2495/:2605).
  *   a, b : scale and shift, a = (energy_max-energy_min)/(2-0.3), b = (energy_max+energy_min)/2 (:3078-3079)

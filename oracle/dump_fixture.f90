@@ -174,6 +174,15 @@ program dump_fixture
       write (u) green_obj%g0(:, :, 1:nen, 1:lattice_obj%nrec)
    case (1)
       write (u) recursion_obj%mu_n
+      ! ---- the stage right after the Chebyshev recursion (self.f90:824): green%chebyshev_green (green.f90:1030-1108)
+      dos_obj = dos(recursion_obj, energy_obj)
+      green_obj = green(dos_obj)
+      call energy_obj%e_mesh()
+      call green_obj%chebyshev_green()
+      nen = energy_obj%channels_ldos + 10
+      write (u) int(z'47524e32'), nen, 0
+      write (u) energy_obj%ene(1:nen)
+      write (u) green_obj%g0(:, :, 1:nen, 1:lattice_obj%nrec)
    case (2)
       write (u) recursion_obj%a(:, :, :, 1)
       write (u) recursion_obj%b2(:, :, :, 1)

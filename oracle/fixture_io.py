@@ -16,6 +16,7 @@ import numpy as np
 
 MAGIC = 0x52534658
 GREEN_MAGIC = 0x47524e31
+CHEB_GREEN_MAGIC = 0x47524e32
 KIND_BLOCK, KIND_CHEB, KIND_SCALAR, KIND_BLOCK_IJ, KIND_CHEB_IJ = 0, 1, 2, 3, 4
 
 
@@ -55,6 +56,10 @@ def read_fixture_bin(path):
             # Green-function stage appended by dump_fixture.f90 for block recursions (self.f90:820-831 run_dos):
             # energies, terminator, sqrt(B^2) (zsqr), g0 = block_green (green.f90:588-621, bgreen :1191-1339)
             gmagic, nen, sym = struct.unpack("<iii", tail)
+            if gmagic == CHEB_GREEN_MAGIC:     # chebyshev_green (green.f90:1030-1108): energies, g0
+                d["green"] = dict(nen=nen, ene=_rd(f, np.float64, (nen,)), g0=_rd(f, np.complex128, (18, 18, nen, nrec)))
+                assert f.read(1) == b"", "trailing bytes in fixture"
+                return d
             assert gmagic == GREEN_MAGIC
             d["green"] = dict(nen=nen, sym_term=sym, ene=_rd(f, np.float64, (nen,)), a_inf=_rd(f, np.float64, (18, 18, nrec)),
                               b_inf=_rd(f, np.float64, (18, 18, nrec)), b_sqrt=_rd(f, np.complex128, (18, 18, lld, nrec)),

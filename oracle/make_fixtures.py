@@ -105,7 +105,7 @@ def run_case(name):
         shutil.rmtree(scratch, ignore_errors=True)
 
 
-GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
+GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh", "bccFe_nsp2_cheb", "fccCu001_cheb"]
 GREEN_STRIDE = 40          # every 40th energy of the reference's mesh (channels_ldos + 10 points) is kept
 
 
@@ -131,6 +131,13 @@ def run_green_case(name):
         d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
         g = d["green"]
         idx = np.arange(0, g["nen"], GREEN_STRIDE, dtype=np.int32)
+        if d["kind"] == fio.KIND_CHEB:
+            out = dict(lld=d["lld"], nrec=d["nrec"], nen_full=g["nen"], ene_idx=idx, ene=g["ene"][idx], emin=d["emin"], emax=d["emax"],
+                       mu_n=d["mu_n"], g0=g["g0"][:, :, idx, :], source_case=np.array(case_dir), namelist_patch=np.array(repr(patch)))
+            path = os.path.join(GOLD, name + "_green.npz")
+            np.savez_compressed(path, **out)
+            print("%-24s chebyshev_green: nen=%d kept=%d nrec=%d lld=%d -> %.1f KB" % (name, g["nen"], len(idx), d["nrec"], d["lld"], os.path.getsize(path) / 1024))
+            return
         out = dict(lld=d["lld"], nrec=d["nrec"], nen_full=g["nen"], sym_term=g["sym_term"], ene_idx=idx, ene=g["ene"][idx],
                    ene_full_first=g["ene"][0], ene_full_step=g["ene"][1] - g["ene"][0],
                    a_inf=g["a_inf"], b_inf=g["b_inf"], a_b=d["a_b"], b_sqrt=g["b_sqrt"], g0=g["g0"][:, :, idx, :],

@@ -140,6 +140,19 @@ def block_green(a_b, b_sqrt, ene, a_inf, b_inf, eta=0.0 + 0.0j, sym_term=False):
     return g0
 
 
+def chebyshev_green(mu_n, ene, emin, emax):
+    """green%chebyshev_green (green.f90:1030) for ONE site: mu_n (18,18,2lld+2) -> g0 (18,18,len(ene))."""
+    mu_n = np.asfortranarray(mu_n, dtype=np.complex128)
+    ene = np.ascontiguousarray(ene, dtype=np.float64)
+    g0 = np.zeros((18, 18, len(ene)), dtype=np.complex128, order="F")
+    L = lib()
+    L.orc_chebyshev_green.restype = C.c_int
+    L.orc_chebyshev_green.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    L.orc_chebyshev_green((mu_n.shape[2] - 2) // 2, len(ene), ene.ctypes.data_as(C.c_void_p), float(emin), float(emax),
+                          mu_n.ctypes.data_as(C.c_void_p), g0.ctypes.data_as(C.c_void_p))
+    return g0
+
+
 def site_partition(rank, nprocs, nsites):
     s, e = C.c_int(), C.c_int()
     lib().orc_site_partition(rank, nprocs, nsites, C.byref(s), C.byref(e))

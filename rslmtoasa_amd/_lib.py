@@ -25,6 +25,7 @@ _SIGNATURES = {
     "rsrec_block_lanczos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_zsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rsrec_chebyshev_green": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "rsrec_block_green": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 5),
     "rsrec_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "rsrec_chebyshev_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]),

@@ -181,4 +181,32 @@ __global__ __launch_bounds__(GREEN_WAVES * 64) void k_block_green(int lld, int n
     for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) out[el] = Q[el]; }
 }
 
+// green%chebyshev_green (green.f90:1030-1108): g0(:,:,ie) = sum_i mu_ng(:,:,i) (-i exp(-i (i-1) acos w_ie)) / sqrt(a^2 - (e_ie - b)^2),
+// mu_ng = mu_n * jackson kernel * (2 for i > 1).  grid = (nen, nsites); the nm phase factors of an energy are formed once in LDS,
+// then every thread sums the moments of its matrix elements in the reference's order (i = 1 .. nm).
+__global__ __launch_bounds__(256) void k_chebyshev_green(int nm, int nen, const double* __restrict__ ene, double a, double b,
+                                                        const double* __restrict__ kern /*[nm] jackson * {1,2,2,...}*/,
+                                                        const double2* __restrict__ mu /*[site][nm][324]*/, double2* __restrict__ g0 /*[site][nen][324]*/) {
+    extern __shared__ double2 ef[];
+    const int ie = blockIdx.x, site = blockIdx.y;
+    const double e = ene[ie];
+    const double th = acos((e - b) / a);
+    for (int i = threadIdx.x; i < nm; i += blockDim.x) {
+        const double x = (double)i * th;                    // (i - 1) with the reference's 1-based i
+        ef[i] = make_double2(-sin(x) * kern[i], -cos(x) * kern[i]);
+    }
+    __syncthreads();
+    const double den = sqrt(a * a - (e - b) * (e - b));
+    const double2* m = mu + (size_t)site * nm * BLK;
+    for (int el = threadIdx.x; el < BLK; el += blockDim.x) {
+        double sr = 0.0, si = 0.0;
+        for (int i = 0; i < nm; ++i) {
+            const double2 v = m[(size_t)i * BLK + el], f = ef[i];
+            sr += v.x * f.x - v.y * f.y;
+            si += v.x * f.y + v.y * f.x;
+        }
+        g0[((size_t)site * nen + ie) * BLK + el] = make_double2(sr / den, si / den);
+    }
+}
+
 }  // namespace rsrec

@@ -924,6 +924,47 @@ extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const
     return RSREC_OK;
 }
 
+// green%chebyshev_green (green.f90:1030-1108): g0 from the Chebyshev moments of every site.
+extern "C" int rsrec_chebyshev_green(rsrec_t* h, int nsites, int lld, int nen, const double* ene, double energy_min, double energy_max,
+                                     const double* mu_n, double* g0) {
+    if (!h) return RSREC_ERR_ARG;
+    if (nsites < 0 || lld < 1 || nen < 0 || (nsites > 0 && nen > 0 && (!ene || !mu_n || !g0))) return fail(h, RSREC_ERR_ARG, "rsrec_chebyshev_green: bad argument");
+    if (nsites == 0 || nen == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    const int nm = 2 * lld + 2;
+    // scale/shift as the reference writes them (default-REAL literals 2 and 0.3, green.f90:1046-1047) and the Jackson kernel
+    // (math.f90:1641-1655; real(ll) is a default-REAL conversion, exact for these small integers)
+    const double a = (energy_max - energy_min) / (double)(2.0f - 0.3f), b = (energy_max + energy_min) / 2;
+    std::vector<double> kern(nm);
+    {
+        const double pi = 3.14159265358979323846;
+        for (int ll = 1; ll <= nm; ++ll) {
+            const double theta = pi * ((double)ll - 1.0) / ((double)nm + 1.0);
+            kern[ll - 1] = (((double)nm - ((double)ll - 1.0) + 1.0) * cos(theta) + sin(theta) / tan(pi / ((double)nm + 1.0))) / ((double)nm + 1.0);
+            if (ll > 1) kern[ll - 1] *= 2.0;                 // mu_ng(:,:,2:) *= 2 (:1074)
+        }
+    }
+    const size_t mbytes = (size_t)nm * BLK * sizeof(double2), gbytes = (size_t)nen * BLK * sizeof(double2);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)1 << 30) / gbytes));
+    HIPCK(h, h->d_green_in.reserve((size_t)chunk * mbytes + (size_t)(nen + nm) * sizeof(double)));
+    HIPCK(h, h->d_green_out.reserve((size_t)chunk * gbytes));
+    double* d_ene = static_cast<double*>(h->d_green_in.p);
+    double* d_kern = d_ene + nen;
+    double2* d_mu = reinterpret_cast<double2*>(d_kern + nm);
+    HIPCK(h, hipMemcpyAsync(d_ene, ene, (size_t)nen * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(d_kern, kern.data(), (size_t)nm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));              // kern is a stack-local vector
+    for (int s0 = 0; s0 < nsites; s0 += chunk) {
+        const int ns = std::min(chunk, nsites - s0);
+        HIPCK(h, hipMemcpyAsync(d_mu, mu_n + (size_t)s0 * nm * BLK * 2, (size_t)ns * mbytes, hipMemcpyHostToDevice, h->stream));
+        k_chebyshev_green<<<dim3(nen, ns), 256, (size_t)nm * sizeof(double2), h->stream>>>(nm, nen, d_ene, a, b, d_kern, d_mu, h->d_green_out.as<double2>());
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipMemcpyAsync(g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    return RSREC_OK;
+}
+
 namespace {
 
 template <class L, bool MFMA>

@@ -36,6 +36,18 @@ class Green:
         self.g0 = g0
         return g0
 
+    def chebyshev_green(self, nsites=None):
+        """green%chebyshev_green (green.f90:1030-1108): g0 from the Chebyshev moments ``recursion.mu_n``."""
+        rec = self.recursion
+        n = rec.mu_n.shape[3] if nsites is None else nsites
+        lld = (rec.mu_n.shape[2] - 2) // 2
+        mu = np.asfortranarray(rec.mu_n[:, :, :, :n])
+        g0 = np.zeros((18, 18, len(self.ene), n), dtype=np.complex128, order="F")
+        rec._check(rec._L.rsrec_chebyshev_green(rec._h, n, lld, len(self.ene), _ptr(self.ene), float(rec.en.energy_min), float(rec.en.energy_max),
+                                                _ptr(mu), _ptr(g0)))
+        self.g0 = g0
+        return g0
+
     def ldos(self):
         """Orbital-resolved local density of states, -Im g0_jj / pi (density_of_states.f90:248-260)."""
         d = np.arange(18)

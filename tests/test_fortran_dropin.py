@@ -54,6 +54,8 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
         # block recursions: the Green function (green%bgreen) also ran on the GPU (fortran/green_gpu.f90); its timer region is
         # listed in the reference's own timing report
         assert "bgreen-gpu" in log, log[-3000:]
+    if "'chebyshev'" in str(case["patch"]):
+        assert "chebyshev-green-gpu" in log, log[-3000:]
     at, rt = case["abs_tol"], case["rel_tol"]
     bad = []
     for fn, keys in case["expected"].get("nml", {}).items():

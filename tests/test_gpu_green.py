@@ -85,3 +85,23 @@ def test_block_green_properties_full_mesh():
     g00 = gr.block_green(a_inf, b_inf)
     assert per_energy_err(g00[:, :, z["ene_idx"], 0], z["g0"][:, :, :, 0]) < RTOL
     rec.close()
+
+
+@pytest.mark.parametrize("name", ["bccFe_nsp2_cheb", "fccCu001_cheb"])
+def test_chebyshev_green(name, oracle_lib):
+    """green%chebyshev_green: (a) reference moments in -> reference g0; (b) GPU Chebyshev recursion -> GPU Green function."""
+    z = load_green(name)
+    g = load_golden(name)
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], emin=g["emin"], emax=g["emax"]), device=0)
+    n = int(z["nrec"])
+    gr = Green(rec, z["ene"])
+    rec.mu_n[:, :, :, :n] = z["mu_n"]
+    g0 = gr.chebyshev_green(nsites=n)
+    for s in range(n):
+        assert per_energy_err(g0[:, :, :, s], z["g0"][:, :, :, s]) < RTOL
+        assert per_energy_err(g0[:, :, :, s], oracle_lib.chebyshev_green(z["mu_n"][:, :, :, s], z["ene"], g["emin"], g["emax"])) < RTOL
+    rec.chebyshev_recur()
+    g0 = gr.chebyshev_green(nsites=n)
+    for s in range(n):
+        assert per_energy_err(g0[:, :, :, s], z["g0"][:, :, :, s]) < RTOL
+    rec.close()
