@@ -87,10 +87,15 @@ struct SpmmArgs {
 // XCD has its own 4 MiB L2.  Every psi block is read by ~15 neighbouring atoms, so groups that are close in the region order
 // must run on the SAME XCD for those re-reads to hit L2: XCD x owns the contiguous chunk x of the group list and its resident
 // workgroups sweep that chunk as a sliding window.  Placement only affects speed, never results.
+// Workgroups that take part in a (chain, level) pass: a function of that chain's group count only, so that the work
+// assignment and the order of the partial sums do not depend on which chains share a launch (batch-size reproducibility);
+// the launch itself is sized by the largest chain of the batch and surplus workgroups leave at once.
+__device__ __forceinline__ int active_workgroups(int ngroups) { return max(1, min((int)gridDim.x, (ngroups + MF_WAVES - 1) / MF_WAVES)); }
+
 struct GroupWalk {
     int g, end, step;
-    __device__ __forceinline__ GroupWalk(int ngroups, int wave) {
-        const int nbx = gridDim.x, bx = blockIdx.x;
+    __device__ __forceinline__ GroupWalk(int ngroups, int wave, int nbx_eff = 0) {
+        const int nbx = nbx_eff > 0 ? nbx_eff : gridDim.x, bx = blockIdx.x;
         const int xcd = bx & 7, j = bx >> 3;
         const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);       // workgroups that share this XCD label
         const int chunk = (ngroups + 7) >> 3;
@@ -258,7 +263,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3;
     GramAcc A;
     A.zero();
-    for (GroupWalk w(ngroups, wave); w.g < w.end; w.g += w.step) {
+    const int nbx = active_workgroups(ngroups);
+    for (GroupWalk w(blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
 #pragma unroll 4
         for (int kq = 0; kq < 36; ++kq) {

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 
     int g, gend, gstep;
     {
-        const int nbx = gridDim.x, bx = blockIdx.x;
+        const int nbx = active_workgroups(ngroups), bx = blockIdx.x;
+        if (bx >= nbx) return;                               // launch sized for the largest chain of the batch
         if (nbx < 8) { g = bx * 4 + gslot; gend = ngroups; gstep = nbx * 4; }
         else {
             const int xcd = bx & 7, j = bx >> 3;

@@ -86,11 +86,13 @@ struct rsrec_handle {
         int nlev, napply, flags, epoch, ostride;
         double atom_steps, block_mults;
         DevBuf order, cum;
+        std::vector<int> level_max;     // per level: largest active-atom count over the chains of this entry
     };
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
     const int* cur_order = nullptr;
     const int* cur_cum = nullptr;     // [nrows][nlev] counts, followed by [nrows][nlev] list offsets
+    const std::vector<int>* cur_level_max = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
 };
@@ -473,7 +475,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     for (auto* e : h->region_cache)
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
-            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb;
+            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
@@ -572,7 +574,10 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     HIPCK(h, hipMemcpyAsync(e->order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync(e->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
-    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb;
+    e->level_max.assign(nlev, 0);
+    for (int c = 0; c < nb; ++c)
+        for (int l = 0; l < nlev; ++l) e->level_max[l] = std::max(e->level_max[l], cum[(size_t)c * nlev + l]);
+    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max;
     return RSREC_OK;
 }
 
@@ -599,9 +604,19 @@ int check_ready(rsrec_t* h, const char* who) {
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 
+// launch size of a (level) pass: enough workgroups for the largest chain of the batch at that level, at most `full.x`
+// (the kernels' own active_workgroups() keeps each chain's work assignment independent of it)
+dim3 level_grid(const rsrec_t* h, dim3 full, int level) {
+    if (!h->cur_level_max || level < 0 || level >= (int)h->cur_level_max->size()) return full;
+    const int groups = (*h->cur_level_max)[level] / GROUP;
+    return dim3(std::max(1, std::min((int)full.x, (groups + MF_WAVES - 1) / MF_WAVES)), full.y);
+}
+
 // store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
 int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
-    if (h->opt_spmm4 != 0 && h->s4_built_split) {
+    // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
+    const bool s4_addressable = (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32);
+    if (h->opt_spmm4 != 0 && h->s4_built_split && s4_addressable) {
         // auto: cooperative (4 waves per group) when there are too few groups to give every wave its own -- it also has the
         // lowest fabric traffic; one wave per group when the launch is large (its per-group overheads amortise better)
         const long groups_max = (long)grid_mf.y * (h->kk / GROUP + 1);
@@ -734,24 +749,26 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<false, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<false, false><<<level_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
                     if (mf_post) {
-                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         if (u_scheme) {
                             // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
-                            k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
-                            if (use_kp) k_mfma_orth3<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                            else k_mfma_orth3<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
-                            k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                            const dim3 gl = level_grid(h, grid_mf, lv_final);
+                            k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                            k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                            if (use_kp) k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                            else k_mfma_orth3<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                            k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                       h->d_status.as<int>());
                             std::swap(psi, t2);
                             hop_ev.emplace_back(e0, e1);
                             h->n_hop_launch += 1;
                             continue;
                         }
+                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
                         if (three_term) {
                             // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
@@ -779,14 +796,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             } else if (u_hoh) {
                 double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
-                k_spmm5<true, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
+                const dim3 g1 = level_grid(h, grid_mf, 2 * ll + 1), gl = level_grid(h, grid_mf, lv_final);
+                k_spmm5<true, false><<<g1, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
                 SD.level = lv_final;
-                k_spmm5<false, true><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
+                k_spmm5<false, true><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
                 e1 = next_event(h);
-                k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
-                k_mfma_orth3<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                           h->d_status.as<int>());
                 std::swap(psi, t2);
                 hop_ev.emplace_back(e0, e1);
@@ -1056,25 +1074,26 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             double* dst = first ? p1 : p2;
             if (mf_cheb) {
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
+                const dim3 gl = level_grid(h, grid_mf, lv_final);
                 if (hoh) {
                     SD.level = 2 * t - 1;
-                    k_spmm5<true, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
+                    k_spmm5<true, false><<<level_grid(h, grid_mf, 2 * t - 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
                     SD.level = lv_final;
-                    k_spmm5<false, true><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
-                } else if (use_kp) k_spmm5<false, false><<<grid_mf, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                    k_spmm5<false, true><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
+                } else if (use_kp) k_spmm5<false, false><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += hoh ? 2 : 1;
                 double* gp = h->d_partial.as<double>();
                 if (first) {
-                    if (use_kp) k_mfma_cheb<true, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
-                    else k_mfma_cheb<true, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
+                    if (use_kp) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
+                    else k_mfma_cheb<true, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
                 } else {
-                    if (use_kp) k_mfma_cheb<false, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
-                    else k_mfma_cheb<false, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
+                    if (use_kp) k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
+                    else k_mfma_cheb<false, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 }
-                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp, grid_mf.x, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp, gl.x, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
                 if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
                 continue;
             }
