@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--spmm4", type=int, default=-1, help="SpMM kernel: 0 = 16x16x4 MFMA, 1 = 4x4x4 MFMA one wave per group, 4 = 4x4x4 cooperative; -1 = library default")
     ap.add_argument("--no-positions", action="store_true", help="do not pass atom positions (locality hint)")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (development sweeps), may be repeated")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-green", action="store_true", help="skip the (untimed, separately reported) Green-function stage")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -136,6 +137,9 @@ def main():
         rec.set_option("batch", args.batch)
     if args.spmm4 >= 0:
         rec.set_option("spmm4", args.spmm4)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        rec.set_option(k, int(v))
 
     from rslmtoasa_amd.parallel import allgather_sites
 
@@ -173,7 +177,7 @@ def main():
 
     if rank == 0:
         default_workload = (args.cells == 22 and args.sites == 64 and args.lld == 50 and not args.kernels and not args.batch
-                            and args.spmm4 < 0 and not args.no_positions)
+                            and args.spmm4 < 0 and not args.no_positions and not args.opt)
         # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + 5.0 * tm_acc["atom_steps"])
         flop_total = flop_rank * world

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth(ChainView CV, in
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }
 
-struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; const int* obase; };
+struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; const int* obase; int nchains = 0; };
 
 // All pointers are separate __restrict__ kernel parameters: only `out` is written, so hipcc can prove the index tables
 // read-only and fetch them with scalar loads (they then never enter the vmcnt queue the operand prefetch relies on).

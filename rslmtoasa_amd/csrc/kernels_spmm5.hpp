@@ -284,10 +284,17 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
                                                const double* __restrict__ in2_all = nullptr) {
-    const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = wave >> 2, gslot = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const unsigned lane_main = 8u * (32 * l4 + 2 * l15), lane_single = 8u * (256 + 16 * (l4 & 1) + l15);
+    const unsigned lane_rem = 8u * (288 + 4 * l4 + 2 * (l15 & 1)), lane_rem_single = 8u * (320 + 2 * (l4 & 1) + (l15 & 1));
+    const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
+    // A workgroup serves the chains blockIdx.y, blockIdx.y + gridDim.y, ...: a 512-thread, 256-register workgroup lives only
+    // 25-50 us per chain, so its launch cost is amortised over several chains (grid.y < number of chains)
+#pragma unroll 1
+    for (int chain = blockIdx.y; chain < D.nchains; chain += gridDim.y) {
     const int count = cum[(chain / D.cpo) * D.nlev + D.level];
     const int ngroups = count / GROUP;
     const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
@@ -296,15 +303,11 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
     const char* __restrict__ in2b = TWO ? reinterpret_cast<const char*>(in2_all + vo) : nullptr;
     double* __restrict__ out = out_all + vo;
     const int zero_block = D.kk;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const unsigned lane_main = 8u * (32 * l4 + 2 * l15), lane_single = 8u * (256 + 16 * (l4 & 1) + l15);
-    const unsigned lane_rem = 8u * (288 + 4 * l4 + 2 * (l15 & 1)), lane_rem_single = 8u * (320 + 2 * (l4 & 1) + (l15 & 1));
-    const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
 
     int g, gend, gstep;
     {
         const int nbx = active_workgroups(ngroups), bx = blockIdx.x;
-        if (bx >= nbx) return;                               // launch sized for the largest chain of the batch
+        if (bx >= nbx) continue;                             // launch sized for the largest chain of the batch
         if (nbx < 8) { g = bx * 4 + gslot; gend = ngroups; gstep = nbx * 4; }
         else {
             const int xcd = bx & 7, j = bx >> 3;
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
             }
         }
     }
+    }   // chains of this workgroup
 }
 
 // LayoutRM -> KP copy of the blocks of one region list (seed blocks; paths whose producer does not write KP itself)

@@ -72,7 +72,7 @@ struct rsrec_handle {
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -268,6 +268,8 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "fuse")) h->opt_fuse = value;
     else if (!strcmp(key, "three_term")) h->opt_three = value;
     else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
+    else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
+    else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -612,6 +614,22 @@ dim3 level_grid(const rsrec_t* h, dim3 full, int level) {
     return dim3(std::max(1, std::min((int)full.x, (groups + MF_WAVES - 1) / MF_WAVES)), full.y);
 }
 
+// k_spmm5 launch: level-sized in x; in y one workgroup per `chain_fold` chains (the kernel loops over them)
+// x: one workgroup per 4 groups of the largest chain (not capped at `full.x`): every workgroup then does at most one round of
+// groups and the hardware dispatcher balances the CUs; with the 256 cap 10 of the 32 workgroups of an XCD did two rounds
+// (measured: folding chains into longer-lived workgroups, i.e. LESS dynamic balancing, costs 10-25 %).
+dim3 s5_grid(const rsrec_t* h, dim3 full, int level) {
+    int gx = full.x;
+    if (h->cur_level_max && level >= 0 && level < (int)h->cur_level_max->size()) {
+        const int groups = (*h->cur_level_max)[level] / GROUP;
+        gx = std::max(1, (groups + MF_WAVES - 1) / MF_WAVES);
+        if (gx > 8) gx = (gx + 7) / 8 * 8;                 // same number of workgroups on every XCD
+        if (h->opt_s5_cap > 0) gx = std::min(gx, (int)h->opt_s5_cap);
+    }
+    const int fold = (int)std::max<long>(1, h->opt_chain_fold);
+    return dim3(gx, (full.y + fold - 1) / fold);
+}
+
 // store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
 int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
     // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
@@ -732,7 +750,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             G.partial = partial;
             if (!hoh) {
                 if (MFMA) {
-                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
+                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase, nb};
                     const double* frag = h->mfma_op.set_ptr(0);
                     if (mf_post && h->opt_fuse) {
                         // fused hop_b: pmn <- H psi - pmn and the A_n partial inside the SpMM kernel
@@ -749,7 +767,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<false, false><<<level_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -795,11 +813,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 }
             } else if (u_hoh) {
                 double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 const dim3 g1 = level_grid(h, grid_mf, 2 * ll + 1), gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<true, false><<<g1, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
+                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
                 SD.level = lv_final;
-                k_spmm5<false, true><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
+                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
                 e1 = next_event(h);
                 k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
@@ -812,7 +830,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 continue;
             } else if (MFMA) {
                 // hoh on the matrix cores: t1 = h psi, t2 = (h o) t1, then the per-atom combine/epilogue (VALU) and MFMA orth/update
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase};
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc;
                 SD.level = lv_final;
                 rc = launch_spmm(h, SD, CV, P, 1, hpsi, t2, grid_mf); if (rc) return rc;
@@ -1073,14 +1091,14 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             double* src = first ? p0 : p1;
             double* dst = first ? p1 : p2;
             if (mf_cheb) {
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase};
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase, nb};
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
                 if (hoh) {
                     SD.level = 2 * t - 1;
-                    k_spmm5<true, false><<<level_grid(h, grid_mf, 2 * t - 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
+                    k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * t - 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
                     SD.level = lv_final;
-                    k_spmm5<false, true><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
-                } else if (use_kp) k_spmm5<false, false><<<gl, 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                    k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
+                } else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
@@ -1098,7 +1116,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 continue;
             }
             if (MFMA) {
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems, CV.obase};
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems, CV.obase, nb};
                 rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc;
                 if (hoh) {
                     SD.level = lv_final;
