@@ -141,6 +141,33 @@ def test_config1_full_size_vs_reference(kernels):
     rec.close()
 
 
+def test_config2_size_1e5_atoms():
+    """BASELINE.json configs[2] size: 46^3 = 97 336 atoms, LL=50, the sites one GPU of eight would own in a small run.
+    No reference output exists at this size (the reference's O(kk^2) cluster builder does not get there), so the check is by
+    properties that do not depend on the size: (1) until a chain can feel the periodic images (level < 11 in the 22^3 cell: a
+    coefficient of level n sums closed paths of at most 2n+1 hops) the 46^3 coefficients equal the compiled reference's
+    22^3 ones; (2) translation invariance; (3) Hermitian A_n, Hermitian positive definite B_n^2 at every level."""
+    g = load_golden("sc_22_block")
+    p = supercell_problem((46, 46, 46))
+    kk = p["nn"].shape[0]
+    assert kk == 97336
+    sites = spread_sites(kk, 4)
+    rec = make(p, sites, int(g["lld"]))
+    rec.recur_b()
+    a_b, b2_b = rec.a_b, rec.b2_b
+    assert rel_err(a_b[:, :, :10, 0], g["a_b"][:, :, :10, 0]) < RTOL
+    assert rel_err(b2_b[:, :, :10, 0], g["b2_b"][:, :, :10, 0]) < RTOL
+    for s in range(1, len(sites)):
+        assert rel_err(a_b[:, :, :, s], a_b[:, :, :, 0]) < RTOL
+        assert rel_err(b2_b[:, :, :, s], b2_b[:, :, :, 0]) < RTOL
+    for ll in range(int(g["lld"])):
+        A, S = a_b[:, :, ll, 0], b2_b[:, :, ll, 0]
+        assert np.abs(A - A.conj().T).max() < 1e-12
+        assert np.abs(S - S.conj().T).max() < 1e-12
+        assert np.linalg.eigvalsh(S).min() > 0
+    rec.close()
+
+
 @pytest.mark.parametrize("opts", [{"three_term": 0}, {"three_term": 1}, {"three_term": 2, "spmm4": 1}, {"three_term": 2, "spmm4": 4},
                                   {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
