@@ -1,0 +1,48 @@
+"""Edge cases of the recursion drivers on the GPU, against the CPU oracle (which mirrors the reference statement by statement):
+shortest recursions (lld = 1, 2), repeated and last-atom seeds, more chains than one batch, zero sites."""
+import numpy as np
+import pytest
+
+from helpers import RTOL, objects_from, rel_err, supercell_problem
+from rslmtoasa_amd.recursion import Recursion, chebyshev_scaling
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lld", [1, 2, 3])
+@pytest.mark.parametrize("hoh", [False, True])
+def test_shortest_recursions(lld, hoh, oracle_lib):
+    p = supercell_problem((4, 4, 8), hoh=hoh)
+    kk = p["nn"].shape[0]
+    sites = np.array([1, kk, 1, 77], dtype=np.int32)          # first atom, last atom, a repeated site
+    rec = Recursion(*objects_from(p, sites, lld, emin=-3.0, emax=1.8), device=0)
+    rec.recur_b()
+    rec.chebyshev_recur()
+    o = oracle_lib.Oracle(p)
+    a_o, b_o = o.block_lanczos(sites, lld)
+    mu_o, rc = o.chebyshev(sites, lld, *chebyshev_scaling(-3.0, 1.8))
+    assert rc == 0
+    if lld > 1:
+        assert rel_err(rec.a_b[:, :, :, :4], a_o) < RTOL
+    else:
+        assert np.all(rec.a_b[:, :, :, :4] == 0) and np.all(a_o == 0)      # a_b(:,:,lld) = 0 (recursion.f90:1836)
+    assert rel_err(rec.b2_b[:, :, :, :4], b_o) < RTOL
+    assert rel_err(rec.mu_n[:, :, :, :4], mu_o) < RTOL
+    assert np.array_equal(rec.a_b[:, :, :, 0], rec.a_b[:, :, :, 2])       # the repeated site gives bit-identical coefficients
+    rec.close()
+
+
+def test_more_chains_than_one_batch_and_zero_sites(oracle_lib):
+    p = supercell_problem((4, 4, 8))
+    kk = p["nn"].shape[0]
+    sites = np.arange(1, kk + 1, dtype=np.int32)              # every atom of the cell: 128 chains = two batches of 64
+    rec = Recursion(*objects_from(p, sites, 6), device=0)
+    rec.recur_b()
+    for s in range(1, kk):                                    # periodic cell of one type: all sites equivalent
+        assert rel_err(rec.a_b[:, :, :, s], rec.a_b[:, :, :, 0]) < RTOL
+    a_o, b_o = oracle_lib.Oracle(p).block_lanczos(sites[:2], 6)
+    assert rel_err(rec.a_b[:, :, :, :2], a_o) < RTOL and rel_err(rec.b2_b[:, :, :, :2], b_o) < RTOL
+    rec.close()
+    rec0 = Recursion(*objects_from(p, np.zeros(0, np.int32), 6), device=0)
+    rec0.recur_b()                                            # no sites on this rank: a no-op, like the reference's empty loop
+    rec0.close()
