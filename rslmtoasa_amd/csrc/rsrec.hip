@@ -70,7 +70,9 @@ struct rsrec_handle {
     int s5_built = 0;
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
-    DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
+    void* pin = nullptr;              // pinned host staging buffer: every per-call transfer goes through it (see xfer_*)
+    size_t pin_bytes = 0;
+    DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
@@ -116,6 +118,8 @@ int fail(rsrec_t* h, int code, const char* fmt, ...) {
     } while (0)
 
 hipEvent_t next_event(rsrec_t* h) {
+    static const bool off = getenv("RSREC_NO_EVENTS") != nullptr;      // diagnostics only
+    if (off) return nullptr;
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -125,6 +129,54 @@ hipEvent_t next_event(rsrec_t* h) {
     (void)hipEventRecord(e, h->stream);
     return e;
 }
+
+// Host <-> device transfers of per-call data go through one pinned staging buffer.  hipMemcpyAsync straight from/to the
+// caller's pageable arrays (freshly allocated numpy / Fortran ALLOCATE memory) was measured at 60-90 ms PER CALL for a 259 KB
+// coefficient download on the MI355X boxes (rocprofv3 --hip-trace: the time is inside hipMemcpyAsync, the GPU idles) --
+// four times the whole single-site recursion.  Staged copies are synchronous by construction (stream order + one wait).
+constexpr size_t PIN_BYTES = (size_t)8 << 20;
+int pin_ready(rsrec_t* h) {
+    if (h->pin) return RSREC_OK;
+    if (hipHostMalloc(&h->pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) { h->pin = nullptr; return fail(h, RSREC_ERR_DEVICE, "hipHostMalloc of the staging buffer failed"); }
+    h->pin_bytes = PIN_BYTES;
+    return RSREC_OK;
+}
+// device -> caller memory; waits for everything queued on the stream before it
+constexpr size_t PIN_MAX_XFER = (size_t)8 << 20;     // larger transfers are bandwidth-, not latency-bound: direct copy (no extra host memcpy)
+int xfer_d2h(rsrec_t* h, void* dst, const void* src_dev, size_t bytes) {
+    if (bytes > PIN_MAX_XFER) {
+        HIPCK(h, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        return RSREC_OK;
+    }
+    int rc = pin_ready(h);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += h->pin_bytes) {
+        const size_t n = std::min(h->pin_bytes, bytes - off);
+        HIPCK(h, hipMemcpyAsync(h->pin, static_cast<const char*>(src_dev) + off, n, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        memcpy(static_cast<char*>(dst) + off, h->pin, n);
+    }
+    return RSREC_OK;
+}
+// caller memory -> device; returns when the data is on the device (the staging buffer is free again)
+int xfer_h2d(rsrec_t* h, void* dst_dev, const void* src, size_t bytes) {
+    if (bytes > PIN_MAX_XFER) {
+        HIPCK(h, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        return RSREC_OK;
+    }
+    int rc = pin_ready(h);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += h->pin_bytes) {
+        const size_t n = std::min(h->pin_bytes, bytes - off);
+        memcpy(h->pin, static_cast<const char*>(src) + off, n);
+        HIPCK(h, hipMemcpyAsync(static_cast<char*>(dst_dev) + off, h->pin, n, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    return RSREC_OK;
+}
+#define XFER(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
 struct Region {
     std::vector<int> order;   // atoms sorted by (distance, index)
@@ -240,13 +292,14 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
-                     &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_coefA, &h->d_coefB, &h->d_bmats,
+                     &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_partial2, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->mfma_op.release();
     h->s4_op.release();
     h->s5_op.release();
+    if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return RSREC_OK;
@@ -573,8 +626,8 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     h->region_cache.push_back(e);
     HIPCK(h, e->order.reserve(order.size() * 4));
     HIPCK(h, e->cum.reserve(cum.size() * 4));
-    HIPCK(h, hipMemcpyAsync(e->order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipMemcpyAsync(e->cum.p, cum.data(), cum.size() * 4, hipMemcpyHostToDevice, h->stream));
+    XFER(xfer_h2d(h, e->order.p, order.data(), order.size() * 4));
+    XFER(xfer_h2d(h, e->cum.p, cum.data(), cum.size() * 4));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
     e->level_max.assign(nlev, 0);
     for (int c = 0; c < nb; ++c)
@@ -628,6 +681,16 @@ dim3 s5_grid(const rsrec_t* h, dim3 full, int level) {
     }
     const int fold = (int)std::max<long>(1, h->opt_chain_fold);
     return dim3(gx, (full.y + fold - 1) / fold);
+}
+
+// Two-stage reduction of per-workgroup partials (k_presum16): returns the buffer and count the final reduce kernel reads.
+const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int width) {
+    if (nblk <= 32) return partial;
+    const int nblk2 = (nblk + 15) / 16;
+    if (h->d_partial2.reserve((size_t)nb * nblk2 * width * sizeof(double)) != hipSuccess) return partial;   // fall back to the single-stage sum
+    k_presum16<<<dim3(nblk2, nb), 256, 0, h->stream>>>(partial, nblk, width, h->d_partial2.as<double>());
+    nblk = nblk2;
+    return h->d_partial2.as<double>();
 }
 
 // store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
@@ -722,8 +785,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         int ostride = kk;
         rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, nsteps, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
-        HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
+        XFER(xfer_h2d(h, h->d_seed.p, seeds0.data(), seeds0.size() * 4));
+        XFER(xfer_h2d(h, h->d_seedcoef.p, coef.data(), coef.size() * 8));
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
 
@@ -776,11 +839,13 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
                             const dim3 gl = level_grid(h, grid_mf, lv_final);
                             k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                            k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                            { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                              k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
                             if (use_kp) k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
                             else k_mfma_orth3<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
-                            k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                      h->d_status.as<int>());
+                            { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                              k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                                        h->d_status.as<int>()); }
                             std::swap(psi, t2);
                             hop_ev.emplace_back(e0, e1);
                             h->n_hop_launch += 1;
@@ -820,10 +885,12 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
                 e1 = next_event(h);
                 k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags);
+                { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                  k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
                 k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(gpartial, gl.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                          h->d_status.as<int>());
+                { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                  k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
+                                                            h->d_status.as<int>()); }
                 std::swap(psi, t2);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += 2;
@@ -860,8 +927,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             k_update<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
         }
         HIPCK(h, hipGetLastError());
-        HIPCK(h, hipMemcpyAsync(a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
-        HIPCK(h, hipMemcpyAsync(b2_b + (size_t)c0 * cstride * 2, dB, (size_t)nb * cstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        XFER(xfer_d2h(h, a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2)));
+        XFER(xfer_d2h(h, b2_b + (size_t)c0 * cstride * 2, dB, (size_t)nb * cstride * sizeof(double2)));
         HIPCK(h, hipStreamSynchronize(h->stream));
     }
     hipEvent_t ev_end = next_event(h);
@@ -870,7 +937,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     for (auto& pr : hop_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);
     h->t_rest_ms = h->t_total_ms - h->t_hop_ms;
     int status = 0;
-    HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
+    XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
     return RSREC_OK;
 }
@@ -905,12 +972,12 @@ extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
     HIPCK(h, h->d_mu.reserve(bytes));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
-    HIPCK(h, hipMemcpyAsync(h->d_mu.p, b2_b, bytes, hipMemcpyHostToDevice, h->stream));
+    XFER(xfer_h2d(h, h->d_mu.p, b2_b, bytes));
     k_zsqr<<<nmat, 256, 0, h->stream>>>(h->d_mu.as<double2>(), h->d_status.as<int>());
     HIPCK(h, hipGetLastError());
-    HIPCK(h, hipMemcpyAsync(b2_b, h->d_mu.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    XFER(xfer_d2h(h, b2_b, h->d_mu.p, bytes));
     int status = 0;
-    HIPCK(h, hipMemcpyAsync(&status, h->d_status.p, 4, hipMemcpyDeviceToHost, h->stream));
+    XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
     return RSREC_OK;
@@ -936,21 +1003,21 @@ extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const
     double2* d_bs = reinterpret_cast<double2*>(reinterpret_cast<char*>(d_ab) + (size_t)chunk * cbytes);
     double* d_ai = reinterpret_cast<double*>(reinterpret_cast<char*>(d_bs) + (size_t)chunk * cbytes);
     double* d_bi = reinterpret_cast<double*>(reinterpret_cast<char*>(d_ai) + (size_t)chunk * tbytes);
-    HIPCK(h, hipMemcpyAsync(d_ene, ene, (size_t)nen * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    XFER(xfer_h2d(h, d_ene, ene, (size_t)nen * sizeof(double)));
     reset_timing(h);
     hipEvent_t ev0 = next_event(h);
     for (int s0 = 0; s0 < nsites; s0 += chunk) {
         const int ns = std::min(chunk, nsites - s0);
-        HIPCK(h, hipMemcpyAsync(d_ab, a_b + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(d_bs, b_sqrt + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(d_ai, a_inf + (size_t)s0 * BLK, (size_t)ns * tbytes, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(d_bi, b_inf + (size_t)s0 * BLK, (size_t)ns * tbytes, hipMemcpyHostToDevice, h->stream));
+        XFER(xfer_h2d(h, d_ab, a_b + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes));
+        XFER(xfer_h2d(h, d_bs, b_sqrt + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes));
+        XFER(xfer_h2d(h, d_ai, a_inf + (size_t)s0 * BLK, (size_t)ns * tbytes));
+        XFER(xfer_h2d(h, d_bi, b_inf + (size_t)s0 * BLK, (size_t)ns * tbytes));
         const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, ns);
         hipEvent_t k0 = next_event(h);
         k_block_green<<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai, d_bi, d_ab, d_bs, h->d_green_out.as<double2>());
         hipEvent_t k1 = next_event(h);
         HIPCK(h, hipGetLastError());
-        HIPCK(h, hipMemcpyAsync(g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes, hipMemcpyDeviceToHost, h->stream));
+        XFER(xfer_d2h(h, g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes));
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_hop_ms += ev_ms(k0, k1);          // reported as "hop_ms": the Green kernel itself; total_ms includes the transfers
     }
@@ -987,15 +1054,15 @@ extern "C" int rsrec_chebyshev_green(rsrec_t* h, int nsites, int lld, int nen, c
     double* d_ene = static_cast<double*>(h->d_green_in.p);
     double* d_kern = d_ene + nen;
     double2* d_mu = reinterpret_cast<double2*>(d_kern + nm);
-    HIPCK(h, hipMemcpyAsync(d_ene, ene, (size_t)nen * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipMemcpyAsync(d_kern, kern.data(), (size_t)nm * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    XFER(xfer_h2d(h, d_ene, ene, (size_t)nen * sizeof(double)));
+    XFER(xfer_h2d(h, d_kern, kern.data(), (size_t)nm * sizeof(double)));
     HIPCK(h, hipStreamSynchronize(h->stream));              // kern is a stack-local vector
     for (int s0 = 0; s0 < nsites; s0 += chunk) {
         const int ns = std::min(chunk, nsites - s0);
-        HIPCK(h, hipMemcpyAsync(d_mu, mu_n + (size_t)s0 * nm * BLK * 2, (size_t)ns * mbytes, hipMemcpyHostToDevice, h->stream));
+        XFER(xfer_h2d(h, d_mu, mu_n + (size_t)s0 * nm * BLK * 2, (size_t)ns * mbytes));
         k_chebyshev_green<<<dim3(nen, ns), 256, (size_t)nm * sizeof(double2), h->stream>>>(nm, nen, d_ene, a, b, d_kern, d_mu, h->d_green_out.as<double2>());
         HIPCK(h, hipGetLastError());
-        HIPCK(h, hipMemcpyAsync(g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes, hipMemcpyDeviceToHost, h->stream));
+        XFER(xfer_d2h(h, g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes));
         HIPCK(h, hipStreamSynchronize(h->stream));
     }
     return RSREC_OK;
@@ -1061,8 +1128,8 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         int ostride = kk;
         rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, napply, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
-        HIPCK(h, hipMemcpyAsync(h->d_seed.p, seeds0.data(), seeds0.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(h->d_seedcoef.p, coef.data(), coef.size() * 8, hipMemcpyHostToDevice, h->stream));
+        XFER(xfer_h2d(h, h->d_seed.p, seeds0.data(), seeds0.size() * 4));
+        XFER(xfer_h2d(h, h->d_seedcoef.p, coef.data(), coef.size() * 8));
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         ChainView CV;
@@ -1111,7 +1178,8 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                     if (use_kp) k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
                     else k_mfma_cheb<false, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 }
-                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp, gl.x, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                int n2 = gl.x; const double* gp2 = presum(h, gp, nb, n2, 2 * 1296);
+                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp2, n2, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
                 if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
                 continue;
             }
@@ -1148,7 +1216,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
         }
         HIPCK(h, hipGetLastError());
-        HIPCK(h, hipMemcpyAsync(mu_n + (size_t)c0 * mstride * 2, mu, (size_t)nb * mstride * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+        XFER(xfer_d2h(h, mu_n + (size_t)c0 * mstride * 2, mu, (size_t)nb * mstride * sizeof(double2)));
         HIPCK(h, hipStreamSynchronize(h->stream));
     }
     hipEvent_t ev_end = next_event(h);
@@ -1157,7 +1225,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     for (auto& pr : hop_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);
     h->t_rest_ms = h->t_total_ms - h->t_hop_ms;
     int status = 0;
-    HIPCK(h, hipMemcpy(&status, h->d_status.p, 4, hipMemcpyDeviceToHost));
+    XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     if (status & 2) return fail(h, RSREC_ERR_DIVERGED, "Chebyshev moments did not converge. Check energy limits energy_min and energy_max");
     return RSREC_OK;
 }
@@ -1233,7 +1301,7 @@ extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_
         rc = upload_regions(h, seeds0.data(), nb, 1, nlev, nsteps, false, false, ostride, dummy1, dummy2);
         if (rc) return rc;
         h->n_atom_steps += dummy1 * NB;
-        HIPCK(h, hipMemcpyAsync(h->d_seed.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, h->stream));
+        XFER(xfer_h2d(h, h->d_seed.p, so.data(), so.size() * 4));
         HIPCK(h, hipStreamSynchronize(h->stream));
         ChainView CV;
         CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = NB; CV.ostride = ostride;
@@ -1250,8 +1318,8 @@ extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_
             h->n_hop_launch += 1;
         }
         HIPCK(h, hipGetLastError());
-        HIPCK(h, hipMemcpyAsync(ha.data(), ca, (size_t)nc * lld * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCK(h, hipMemcpyAsync(hb.data(), cb, (size_t)nc * lld * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        XFER(xfer_d2h(h, ha.data(), ca, (size_t)nc * lld * sizeof(double)));
+        XFER(xfer_d2h(h, hb.data(), cb, (size_t)nc * lld * sizeof(double)));
         HIPCK(h, hipStreamSynchronize(h->stream));
         for (int q = 0; q < nc; ++q)
             for (int ll = 0; ll < lld; ++ll) {
