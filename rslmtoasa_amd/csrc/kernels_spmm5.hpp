@@ -36,6 +36,15 @@ __host__ __device__ constexpr int kp_offset(int r, int part, int c) {
     return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
 }
 
+#ifndef S5_WG_GROUPS
+#define S5_WG_GROUPS 4   // groups of 8 atoms per workgroup (x 2 spin waves each): 4 -> 512 threads, 2 -> 256 threads
+#endif
+#ifndef S5_VARIANT
+#define S5_VARIANT 0     // development A/B switches, measured on one box against 0 (5.43-5.47 ms per level):
+                         //   1 = operand loads not interleaved with the MFMAs (+2.5 %), 2 = no scheduling fence between steps (+0.6 %),
+                         //   3 = plain round-robin group walk instead of XCD chunks (+13 %), 4 = loads front-loaded in the step (+0.6 %),
+                         //   5 = different s_setprio for the two spin waves (+0.7 %);  S5_WG_GROUPS = 2 (256-thread workgroups): +15 %
+#endif
 #ifndef S5_PROBE
 #define S5_PROBE 0   // timing probes only: 1 = no operator-fragment loads in the slot loop, 2 = no psi loads (results wrong)
 #endif
@@ -182,7 +191,8 @@ __device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, uns
 // issue order: one operand load, then PER MFMAs (see k_spmm4's s4_interleave)
 template <int NL, int NM>
 __device__ __forceinline__ void s5_interleave() {
-    constexpr int PER = NM / NL;
+    if (S5_VARIANT == 1) return;
+    constexpr int PER = (S5_VARIANT == 4) ? NM / (2 * NL) : NM / NL;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
@@ -248,6 +258,7 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     S5Single Z;
     s5_load_pair<0, false>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
     if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+    if (S5_VARIANT == 5) { if (sig) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
     for (int j = 0; j < nmine; ++j) {
         const int e_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last entry prefetches the first again (discarded)
         load_idx(e_nxt & 255, nraw, nrem);
@@ -259,16 +270,16 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
         s5_load_pair<1>(Y, cur, so, fb, lane_main, lane_rem, lane16);
         s5_mfma_pair(acc, X);
         s5_interleave<14, 90>();
-        __builtin_amdgcn_sched_barrier(0);
+        if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
         s5_load_single(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
         s5_mfma_pair(acc, Y);
         s5_interleave<14, 90>();
-        __builtin_amdgcn_sched_barrier(0);
+        if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
         make_slot(nraw, nrem, cur, e_nxt & 255);        // the current entry's operands are all in flight or consumed: reuse its state
         s5_load_pair<0>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
         s5_mfma_single(acc, Z);
         s5_interleave<14, 45>();
-        __builtin_amdgcn_sched_barrier(0);
+        if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
         e_cur = e_nxt;
         e_nxt = e_nxt2;
     }
@@ -279,14 +290,14 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 // OUT_KP: write the result in the KP layout instead (first pass of hoh: its result is only read by the second pass).
 // TWO: second input vector for the extra on-site slot (second pass of hoh).
 template <bool OUT_KP, bool TWO>
-__global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
+__global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
                                                const double* __restrict__ in2_all = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sig = wave >> 2, gslot = wave & 3;
+    const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
     const int l15 = lane & 15, l4 = lane >> 4;
     const unsigned lane_main = 8u * (32 * l4 + 2 * l15), lane_single = 8u * (256 + 16 * (l4 & 1) + l15);
     const unsigned lane_rem = 8u * (288 + 4 * l4 + 2 * (l15 & 1)), lane_rem_single = 8u * (320 + 2 * (l4 & 1) + (l15 & 1));
@@ -306,17 +317,17 @@ __global__ __launch_bounds__(512) void k_spmm5(SpmmDims D, const int* __restrict
 
     int g, gend, gstep;
     {
-        const int nbx = active_workgroups(ngroups), bx = blockIdx.x;
+        const int nbx = max(1, min((int)gridDim.x, (ngroups + S5_WG_GROUPS - 1) / S5_WG_GROUPS)), bx = blockIdx.x;
         if (bx >= nbx) continue;                             // launch sized for the largest chain of the batch
-        if (nbx < 8) { g = bx * 4 + gslot; gend = ngroups; gstep = nbx * 4; }
+        if (nbx < 8 || S5_VARIANT == 3) { g = bx * S5_WG_GROUPS + gslot; gend = ngroups; gstep = nbx * S5_WG_GROUPS; }
         else {
             const int xcd = bx & 7, j = bx >> 3;
             const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
             const int chunk = (ngroups + 7) >> 3;
             const int lo = xcd * chunk;
             gend = min(ngroups, lo + chunk);
-            g = lo + j * 4 + gslot;
-            gstep = per_xcd * 4;
+            g = lo + j * S5_WG_GROUPS + gslot;
+            gstep = per_xcd * S5_WG_GROUPS;
         }
     }
     for (; g < gend; g += gstep) {

@@ -675,7 +675,7 @@ dim3 s5_grid(const rsrec_t* h, dim3 full, int level) {
     int gx = full.x;
     if (h->cur_level_max && level >= 0 && level < (int)h->cur_level_max->size()) {
         const int groups = (*h->cur_level_max)[level] / GROUP;
-        gx = std::max(1, (groups + MF_WAVES - 1) / MF_WAVES);
+        gx = std::max(1, (groups + S5_WG_GROUPS - 1) / S5_WG_GROUPS);
         if (gx > 8) gx = (gx + 7) / 8 * 8;                 // same number of workgroups on every XCD
         if (h->opt_s5_cap > 0) gx = std::min(gx, (int)h->opt_s5_cap);
     }
@@ -830,7 +830,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -880,9 +880,9 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 const dim3 g1 = level_grid(h, grid_mf, 2 * ll + 1), gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
+                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
                 SD.level = lv_final;
-                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
+                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
                 e1 = next_event(h);
                 k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
@@ -1162,10 +1162,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
                 if (hoh) {
                     SD.level = 2 * t - 1;
-                    k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * t - 1), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
+                    k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * t - 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
                     SD.level = lv_final;
-                    k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
-                } else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), 512, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                    k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
+                } else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
