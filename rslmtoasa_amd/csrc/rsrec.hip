@@ -659,6 +659,15 @@ int check_ready(rsrec_t* h, const char* who) {
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 
+// Workgroups per chain of the matrix-core post-hop kernels (Gram, orthogonalisation, Chebyshev step): they hold their 36x36
+// coefficient tables in registers and run one wave per SIMD, so long-lived waves win -- about two workgroups per CU over
+// the whole batch (measured at 64 chains: 8 per chain 4.3 ms per level, 64 per chain 5.0 ms).  Three fixed bands, so that the
+// work assignment (and with it the rounding of the reductions) only changes when the batch size crosses a band.
+int mfma_workgroups_per_chain(const rsrec_t* h, int batch) {
+    if (h->opt_nblk > 0) return (int)std::min<long>(2 * h->opt_nblk, 256);
+    return batch >= 32 ? 8 : (batch >= 16 ? 32 : 256);
+}
+
 // launch size of a (level) pass: enough workgroups for the largest chain of the batch at that level, at most `full.x`
 // (the kernels' own active_workgroups() keeps each chain's work assignment independent of it)
 dim3 level_grid(const rsrec_t* h, dim3 full, int level) {
@@ -803,7 +812,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         double* ukp = (use_kp || u_hoh) ? h->d_vec[4].as<double>() : nullptr;
         if (use_kp || u_hoh) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
         const dim3 grid(nblk, nb);
-        const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+        const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
             const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
             const double* tvec = nullptr;                      // H psi when it is held in a vector of its own
@@ -1141,7 +1150,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         double* p2 = h->d_vec[2].as<double>();
         double* tmp = h->d_vec[3].as<double>();
         double* tmp2 = h->d_vec[4].as<double>();
-        const dim3 grid_mf(std::max(1, std::min(std::min(nblk * 2, 256), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+        const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)
         double* vkp = use_kp ? tmp2 : nullptr;                  // k-pair copy of the vector the next SpMM reads
