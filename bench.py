@@ -35,9 +35,9 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); ra
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
 # Memory-side bytes per H|psi> launch of the DEFAULT workload (22^3 atoms, 64 sites, LL=50), from separate rocprofv3 --pmc passes
-# (profiles/r01_final_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 35.3 GB + 3.2 GB.
+# (profiles/r01_final_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 29.2 GB + 3.0 GB.
 # The counters sit on the L2's fabric side, so Infinity-Cache hits of the neighbour gathers are included.
-HOP_TRAFFIC_BYTES_PER_LAUNCH = 38.5e9
+HOP_TRAFFIC_BYTES_PER_LAUNCH = 32.2e9
 CPU_SAMPLE_SITES = 10
 BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
 
