@@ -116,10 +116,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # one process per GPU.  BENCH_REHEARSAL=1 (development only): several ranks share the GPUs that exist and talk over gloo,
+    # to exercise the N > 1 code path on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    device_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
+    coll_device = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        torch.cuda.set_device(device_index)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))   # "nccl" is RCCL on ROCm
 
     ee, lsham, slot_vec = load_stencil()
     n = args.cells
@@ -130,7 +138,7 @@ def main():
     lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1, cr=None if args.no_positions else supercell_positions((n, n, n)))
     ham = Hamiltonian(ee=ee, lsham=lsham, hoh=False)
     ctl = Control(lld=args.lld, nsp=2, recur="block")
-    rec = Recursion(ham, lat, ctl, Energy(), device=local_rank, rank=rank, nprocs=world)   # uploads tables: resident before timing
+    rec = Recursion(ham, lat, ctl, Energy(), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
     if args.kernels:
         rec.set_option("kernels", args.kernels)
     if args.batch:
@@ -150,7 +158,7 @@ def main():
             # here the diagonal coefficients a(ll,l,site), b2(ll,l,site) that feed the LDOS continued fraction
             start, end = rec._my_sites()[:2]
             nloc = end - start + 1
-            allgather_sites([rec.a[:args.lld, :, :nloc, 0], rec.b2[:args.lld, :, :nloc, 0]], rank, world, nsites_total, dist=dist, device="cuda")
+            allgather_sites([rec.a[:args.lld, :, :nloc, 0], rec.b2[:args.lld, :, :nloc, 0]], rank, world, nsites_total, dist=dist, device=coll_device)
 
     for _ in range(args.warmup):
         step()
@@ -171,7 +179,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
