@@ -16,7 +16,10 @@
 
 namespace rsrec {
 
-constexpr int GREEN_WAVES = 4;                                   // (site, energy) pairs per workgroup
+#ifndef GREEN_WAVES_N
+#define GREEN_WAVES_N 2     // measured: 1 -> 123 ms, 2 -> 118 ms, 3 -> 128 ms, 4 -> 130 ms, 5 -> 187 ms (64 sites x 2510 energies x LL=50): LDS slice = occupancy
+#endif
+constexpr int GREEN_WAVES = GREEN_WAVES_N;                       // (site, energy) pairs per workgroup
 constexpr int GREEN_LDS_DOUBLES = GREEN_WAVES * (3 * 2 * BLK + 32);   // Q, X, B (complex) + pivot rows, per wave
 
 __device__ __forceinline__ void wave_sync() {
