@@ -23,6 +23,17 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GROUP = 8;            // atoms per wave (one type)
 constexpr int MF_WAVES = 4;         // waves per workgroup
+
+// element (orbital row r, re/im part, column c) of an 18x18 complex block in the KP layout (648 doubles, a bijection):
+// per spin sigma = r / 9 a 324-double half; real-form row w = 9 part + m (m = r % 9), k-pair p = w >> 3, lane row l4 = w & 3,
+// pair member e = (w >> 2) & 1; rows 16, 17 form the spin's fifth (half-empty) k-step.
+__host__ __device__ constexpr int kp_offset(int r, int part, int c) {
+    const int sigma = r / 9, m = r % 9, w = 9 * part + m, base = 324 * sigma;
+    if (c < 16) return w < 16 ? base + 128 * (w >> 3) + 32 * (w & 3) + 2 * c + ((w >> 2) & 1) : base + 256 + 16 * (w - 16) + c;
+    const int cc = c - 16;
+    return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
+}
+
 constexpr int FRAG_PER_SLOT = 9 * 3 * 64;   // doubles: [q][f][lane]
 
 // Host-side builder + device storage of the fragment tables.
@@ -249,9 +260,16 @@ __device__ __forceinline__ void gram_block_out(const GramAcc& A, double* lds /*[
 }
 
 // ---- A_n partial: Gm = sum_rows psihat^T * that   (hop_b :1642) -------------------------------------------------------
+// PSI_KP: psi is stored in the k-pair layout (kp_offset)
+template <bool PSI_KP>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, int level, int zero_block, const double* __restrict__ psi,
                                                                const double* __restrict__ tvec, double* partial /*[chain][nblk][1296]*/) {
     __shared__ double lds[MF_WAVES * 1296];
+    __shared__ unsigned short kpt[PSI_KP ? BLD : 1];
+    if (PSI_KP) {
+        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
+        __syncthreads();
+    }
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -269,7 +287,12 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
 #pragma unroll 4
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);               // k-row of this lane
-            const double p0 = ps[rk.off + l15], p1 = ps[rk.off + 16 + l15], pr = ps[rk.off + 32 + l3];
+            double p0, p1, pr;
+            if (PSI_KP) {
+                const unsigned blk = (rk.off / BLD) * BLD;
+                const unsigned short* t = kpt + (rk.off - blk);
+                p0 = ps[blk + t[l15]]; p1 = ps[blk + t[16 + l15]]; pr = ps[blk + t[32 + l3]];
+            } else { p0 = ps[rk.off + l15]; p1 = ps[rk.off + 16 + l15]; pr = ps[rk.off + 32 + l3]; }
             const double h0 = tv[rk.off + l15], h1 = tv[rk.off + 16 + l15], hr = tv[rk.off + 32 + l3];
             A.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h0, A.t00, 0, 0, 0);
             A.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h1, A.t01, 0, 0, 0);

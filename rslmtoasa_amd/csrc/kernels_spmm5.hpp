@@ -26,15 +26,7 @@
 
 namespace rsrec {
 
-// element (orbital row r, re/im part, column c) of an 18x18 complex block in the KP layout (648 doubles, a bijection):
-// per spin sigma = r / 9 a 324-double half; real-form row w = 9 part + m (m = r % 9), k-pair p = w >> 3, lane row l4 = w & 3,
-// pair member e = (w >> 2) & 1; rows 16, 17 form the spin's fifth (half-empty) k-step.
-__host__ __device__ constexpr int kp_offset(int r, int part, int c) {
-    const int sigma = r / 9, m = r % 9, w = 9 * part + m, base = 324 * sigma;
-    if (c < 16) return w < 16 ? base + 128 * (w >> 3) + 32 * (w & 3) + 2 * c + ((w >> 2) & 1) : base + 256 + 16 * (w - 16) + c;
-    const int cc = c - 16;
-    return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
-}
+// (kp_offset, the element map of the KP layout, lives in kernels_mfma.hpp: the Gram / orthogonalisation kernels read KP vectors too)
 
 #ifndef S5_WG_GROUPS
 #define S5_WG_GROUPS 4   // groups of 8 atoms per workgroup (x 2 spin waves each): 4 -> 512 threads, 2 -> 256 threads

@@ -60,6 +60,15 @@ __device__ __forceinline__ void u3_load(U3Operands& o, const double* __restrict_
     o.y = base[off + 32 + l4];
 }
 
+// the same operands from a vector stored in the KP layout only: off = BLD * atom + 36 r (LayoutRM row reference), kpt = element map
+__device__ __forceinline__ void u3_load_kp(U3Operands& o, const double* __restrict__ base, unsigned off, int l4, const unsigned short* kpt) {
+    const unsigned blk = (off / BLD) * BLD;
+    const unsigned short* t = kpt + (off - blk) + 2 * l4;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { o.x[qq].x = base[blk + t[8 * qq]]; o.x[qq].y = base[blk + t[8 * qq + 1]]; }
+    o.y = base[blk + kpt[(off - blk) + 32 + l4]];
+}
+
 template <int Q>
 __device__ __forceinline__ double u3_k(const U3Operands& o) { return Q < 8 ? ((Q & 1) ? o.x[Q >> 1].y : o.x[Q >> 1].x) : o.y; }
 
@@ -79,8 +88,9 @@ __device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr,
 // tabs[chain][3][27*64]: T1 = Binv_n, T2 = -Binv_{n-1} B_n, T3 = -Binv_n A_n (paired-k fragment tables).
 // One wave per SIMD (the three tables live in registers); the next row tile's operands are fetched before the current
 // tile's MFMAs so each wave keeps ~14 KB of reads in flight.
-// KP = true: u_next is also written in the k-pair layout the next level's SpMM (k_spmm5) reads.
-template <bool KP>
+// KP = 1: u_next is also written in the k-pair layout the next level's SpMM (k_spmm5) reads.
+// KP = 2: the u vectors exist in the KP layout ONLY (ucur, uprev are KP vectors; t' stays LayoutRM): one block stream less.
+template <int KP>
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                 const double* __restrict__ ucur, double* uprev,
                                                                 const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/,
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     const double* tv = tvec + vo;
     const double* uc = ucur + vo;
     double* up = uprev + vo;
-    double* uk = KP ? ukp_all + vo : nullptr;
+    double* uk = KP == 2 ? up : (KP ? ukp_all + vo : nullptr);
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     double T1[27], T2[27], T3[27];
     {
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
         it = min(it, ntile - 1);
         const int g = w.g + (it / 9) * w.step;
         const RowRef ra = group_row(order + (size_t)g * GROUP, 16 * (it % 9) + l15, zero_block);
-        u3_load(a, tv, ra.off, l4); u3_load(c, uc, ra.off, l4); u3_load(p, up, ra.off, l4);
+        u3_load(a, tv, ra.off, l4);
+        if (KP == 2) { u3_load_kp(c, uc, ra.off, l4, kpt); u3_load_kp(p, up, ra.off, l4, kpt); }
+        else { u3_load(c, uc, ra.off, l4); u3_load(p, up, ra.off, l4); }
     };
     U3Operands ot, oc, op, nt, nc, np;
     if (ntile > 0) { load_tile(0, ot, oc, op); load_tile(1, nt, nc, np); }
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
         for (int j = 0; j < 4; ++j) {
             const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
             if (rs.valid) {
-                up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j];
+                if (KP != 2) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
                 if (KP) {
                     const unsigned blk = (rs.off / BLD) * BLD, e0 = rs.off - blk;      // block base, 36 r
                     uk[blk + kpt[e0 + l15]] = ca[j]; uk[blk + kpt[e0 + 16 + l15]] = cb[j];
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
         }
         const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
         if (rr.valid) {
-            up[rr.off + 32 + l3] = cr;
+            if (KP != 2) up[rr.off + 32 + l3] = cr;
             if (KP) { const unsigned blk = (rr.off / BLD) * BLD; uk[blk + kpt[rr.off - blk + 32 + l3]] = cr; }
         }
 #pragma unroll

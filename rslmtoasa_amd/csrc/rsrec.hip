@@ -74,7 +74,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_kp_only = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -323,6 +323,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
+    else if (!strcmp(key, "kp_only")) h->opt_kp_only = value;
     else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -811,6 +812,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         if (u_scheme || u_hoh) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
         double* ukp = (use_kp || u_hoh) ? h->d_vec[4].as<double>() : nullptr;
         if (use_kp || u_hoh) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
+        // kp_only (option, off): the u vectors live in the KP layout only (psi / t2 then name the two KP buffers; t' = hpsi stays
+        // LayoutRM): the orthogonalisation kernel writes one copy of u_next instead of two.  Measured 7 % SLOWER post-hop
+        // (4.70 vs 4.40 ms per level): the 8-byte gathers of the u operands from the KP layout cost more than the saved stream.
+        const bool kp_only = (use_kp || u_hoh) && h->opt_kp_only;
+        if (kp_only) psi = ukp;
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         for (int ll = 0; ll < nsteps; ++ll) {
@@ -839,7 +845,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hpsi);
+                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), kp_only ? psi : ukp, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -847,11 +853,13 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         if (u_scheme) {
                             // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
                             const dim3 gl = level_grid(h, grid_mf, lv_final);
-                            k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                            if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                            else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                             { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                               k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                            if (use_kp) k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                            else k_mfma_orth3<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                            if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                            else if (use_kp) k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                            else k_mfma_orth3<0><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
                             { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                               k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                                         h->d_status.as<int>()); }
@@ -860,7 +868,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             h->n_hop_launch += 1;
                             continue;
                         }
-                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                        k_mfma_adot<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
                         if (three_term) {
                             // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
@@ -889,14 +897,16 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 const dim3 g1 = level_grid(h, grid_mf, 2 * ll + 1), gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), ukp, hkp);
+                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), kp_only ? psi : ukp, hkp);
                 SD.level = lv_final;
-                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, ukp);
+                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, kp_only ? psi : ukp);
                 e1 = next_event(h);
-                k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                   k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                k_mfma_orth3<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
+                if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
+                else k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                   k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
                                                             h->d_status.as<int>()); }

@@ -170,7 +170,7 @@ def test_config2_size_1e5_atoms():
 
 
 @pytest.mark.parametrize("opts", [{"three_term": 0}, {"three_term": 1}, {"three_term": 2, "spmm4": 1}, {"three_term": 2, "spmm4": 4},
-                                  {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}])
+                                  {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}, {"spmm5": 2, "kp_only": 1}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """The alternative pipelines kept in the library (reference order, normalised three-term, un-normalised; each SpMM kernel)
