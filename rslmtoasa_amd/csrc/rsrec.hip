@@ -755,6 +755,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2)));
+    HIPCK(h, h->d_partial2.reserve((size_t)B * 16 * 2 * 1296 * sizeof(double)));      // second stage of the partial sums (presum): sized once, never grown mid-stream
     HIPCK(h, h->d_frags.reserve((size_t)B * 4 * 27 * 64 * sizeof(double)));
     HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
@@ -1112,6 +1113,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve(std::max((size_t)B * nblk * 2 * BLK * sizeof(double2), (size_t)B * 256 * 2 * 1296 * sizeof(double))));
+    HIPCK(h, h->d_partial2.reserve((size_t)B * 16 * 2 * 1296 * sizeof(double)));
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
