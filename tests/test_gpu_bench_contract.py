@@ -1,0 +1,43 @@
+"""bench.py contract on the GPU box: one JSON line with the required keys at N = 1, and the N = 2 code path (site partition x2,
+max-over-ranks timing, packed all-reduce of the results) rehearsed with two ranks sharing the one GPU over gloo
+(BENCH_REHEARSAL=1; on the 8-GPU node the same code runs over RCCL with one rank per device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline"}
+
+
+def last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_small():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--sites", "8", "--cells", "10", "--lld", "12",
+                        "--no-green"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.2
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--sites", "8", "--cells", "10", "--lld", "12"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"] and d["value"] > 0
+    assert "cpu_baseline" not in d                    # CPU leg on rank 0 at N = 1 only
