@@ -134,12 +134,23 @@ void rsrec_site_partition(int rank, int nprocs, int nsites, int *start_atom, int
 int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
 
 /* ---- tuning / measurement (not part of the reference interface) ---- */
-/* key/value knobs: "batch" (chains advanced together, 0 = auto), "kernels" (0 = auto, 1 = VALU reference kernels, 2 = MFMA) */
+/* key/value knobs (defaults in brackets; everything but "batch" and "kernels" exists for A/B measurements and tests):
+ *   "batch"      chains advanced together per launch [0 = auto: up to 64, bounded by free device memory]
+ *   "kernels"    0 = auto, 1 = FP64 VALU kernel set (reference layout), 2 = matrix-core kernel set [0]
+ *   "three_term" block Lanczos formulation: 0 = the reference's literal order, 1 = normalised three-term, 2 = un-normalised (u-scheme) [2]
+ *   "spmm4"      small-launch SpMM: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative [-1]
+ *   "spmm5"      large-launch SpMM k_spmm5: 0 off, 1 auto (>= 4096 groups per launch; always for hoh), 2 always [1]
+ *   "kp_only"    u vectors in the k-pair layout only (measured slower) [0]
+ *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
+ *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none]
+ *   "post", "fuse", "wps"  older pipeline variants kept for cross-checks [0, 0, 1] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
 /* Timing of the last recursion call, measured with HIP events on the engine's own stream:
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,
  *   out[3] atom-steps processed (sum over chains and steps of active atoms), out[4] block multiplies in H|psi>,
- *   out[5] ms in the remaining recursion kernels, out[6] host ms (region bookkeeping + transfers) */
+ *   out[5] ms in the remaining recursion kernels, out[6] host ms (region bookkeeping + transfers),
+ *   out[7] 1 if the timed H|psi> kernel also forms the A_n partial (VALU / fused variants), else 0.
+ * After rsrec_block_green: out[0] = kernel + transfers, out[1] = the Green kernel alone. */
 int rsrec_get_timing(rsrec_t *h, double *out, int n);
 
 #ifdef __cplusplus
