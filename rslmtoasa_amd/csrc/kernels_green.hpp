@@ -17,101 +17,191 @@
 namespace rsrec {
 
 #ifndef GREEN_WAVES_N
-#define GREEN_WAVES_N 2     // measured: 1 -> 123 ms, 2 -> 118 ms, 3 -> 128 ms, 4 -> 130 ms, 5 -> 187 ms (64 sites x 2510 energies x LL=50): LDS slice = occupancy
+#define GREEN_WAVES_N 4
 #endif
 constexpr int GREEN_WAVES = GREEN_WAVES_N;                       // (site, energy) pairs per workgroup
-constexpr int GREEN_LDS_DOUBLES = GREEN_WAVES * (3 * 2 * BLK + 32);   // Q, X, B (complex) + pivot rows, per wave
+
+// LDS slice of one wave.  The running matrix itself lives in REGISTERS: lane (ig, jg) = (lane / 6, lane % 6), lanes 0..53, owns
+// the 2 x 3 block rows {2 ig, 2 ig + 1} x columns {3 jg .. 3 jg + 2}.  LDS carries what has to cross lanes: the pivot column and
+// one or two rows per elimination step, and the operands of the two products (each lane reads 2 rows / 3 columns per k: 5
+// 16-byte loads for 6 complex FMAs).  The all-in-LDS formulation this replaces kept the LDS pipe 72 % busy (tools/pmc_green.sh).
+struct GreenLds {
+    double2 M[BLK];        // staging of a whole matrix for the products (Q^-1, then X), column-major
+    double2 B[BLK];        // B_l
+    double2 col[NB], rowk[NB], rowp[NB];
+    int piv[NB + 2];
+};
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ double2 gmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 gmul(double2 a, double2 b) { return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)); }
+// s + a b,  s - a b,  s + conj(a) b  as explicit FMA chains (4 instructions each)
+__device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 s) { return make_double2(fma(-a.y, b.y, fma(a.x, b.x, s.x)), fma(a.y, b.x, fma(a.x, b.y, s.y))); }
+__device__ __forceinline__ double2 cfms(double2 a, double2 b, double2 s) { return make_double2(fma(a.y, b.y, fma(-a.x, b.x, s.x)), fma(-a.y, b.x, fma(-a.x, b.y, s.y))); }
+__device__ __forceinline__ double2 cfmah(double2 a, double2 b, double2 s) { return make_double2(fma(a.y, b.y, fma(a.x, b.x, s.x)), fma(-a.y, b.x, fma(a.x, b.y, s.y))); }
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double2 sel(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 
-// in-place inverse of the 18x18 complex matrix M (column-major, in this wave's LDS slice); piv: 18 ints of LDS scratch
-__device__ __forceinline__ void wave_inverse18(double2* M, int* piv, int lane) {
-#pragma unroll 1
-    for (int k = 0; k < NB; ++k) {
-        // pivot: first row i >= k of maximal |re| + |im| in column k
-        double v = -1.0;
-        int idx = lane;
-        if (lane >= k && lane < NB) { const double2 x = M[lane + NB * k]; v = fabs(x.x) + fabs(x.y); }
+// row-of-16 shift of a double on the DPP crossbar (no LDS traffic): lane i takes lane i - n of its row, lanes 0..n-1 keep their own
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// One Gauss-Jordan step (column K, a compile-time constant: every register index below is static) of the in-place inverse with
+// partial pivoting.  Row interchange k <-> p, then  M'[i][j] = x[i][j] - f_i r_j  with  r = (row k with M[k][k] := 1) / pivot,
+// f = column k with f_k := -1, x = M with row k and column k zeroed.  Row K sits in register row K & 1 of the lanes ig == K >> 1,
+// column K in register column K % 3 of the lanes jg == K / 3: only those registers carry a select.
+template <int K>
+__device__ __forceinline__ void gauss_jordan_step(double2 (&q)[2][3], GreenLds& L, int lane, int ig, int jg, bool act) {
+    constexpr int KR = K & 1, KIG = K >> 1, KC = K % 3, KJG = K / 3;
+    // the lane predicates of a step are two compares; keep the compiler from hoisting 18 steps' worth of masks out of the level loop
+    int igp = ig, jgp = jg;
+    asm volatile("" : "+v"(igp), "+v"(jgp));
+    const bool in_row = igp == KIG, in_col = jgp == KJG;
+    if (act && in_col) { L.col[2 * ig] = q[0][KC]; L.col[2 * ig + 1] = q[1][KC]; }
+    if (act && in_row) { L.rowk[3 * jg] = q[KR][0]; L.rowk[3 * jg + 1] = q[KR][1]; L.rowk[3 * jg + 2] = q[KR][2]; }
+    wave_sync();
+    // pivot: first row i >= K of maximal |re| + |im| (izamax): maximum by a DPP scan of the two 16-lane rows that hold the 18
+    // candidates, then the first lane that attains it
+    double2 cx = make_double2(0.0, 0.0);
+    double v = -1.0;
+    if (lane < NB) { cx = L.col[lane]; if (lane >= K) v = fabs(cx.x) + fabs(cx.y); }
+    double m = fmax(v, dpp_d<0x111>(v));
+    m = fmax(m, dpp_d<0x112>(m));
+    m = fmax(m, dpp_d<0x114>(m));
+    m = fmax(m, dpp_d<0x118>(m));
+    const double vmax = fmax(readlane_d(m, 15), readlane_d(m, 31));
+    const unsigned long long hit = __ballot(v == vmax);
+    const int p = hit ? (int)__builtin_ctzll(hit) : K;
+    if (lane == 0) L.piv[K] = p;
+    const double2 pv = make_double2(readlane_d(cx.x, p), readlane_d(cx.y, p));      // pivot = M[p][K]
+    const double rden = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+    const double2 ip = make_double2(pv.x * rden, -pv.y * rden);
+    const double2* prow = L.rowk;
+    if (p != K) {                                                // wave-uniform: rows K and p change places
+        const int pig = p >> 1;
+        const bool odd = p & 1, mine = act && igp == pig;
+        if (mine) {
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            const double v2 = __shfl_xor(v, off, 64);
-            const int i2 = __shfl_xor(idx, off, 64);
-            if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+            for (int c = 0; c < 3; ++c) L.rowp[3 * jg + c] = sel(odd, q[1][c], q[0][c]);
         }
-        const int p = __builtin_amdgcn_readfirstlane(idx);
-        if (lane == 0) piv[k] = p;
-        if (p != k && lane < NB) {                               // swap rows k and p
-            const double2 a = M[k + NB * lane], b = M[p + NB * lane];
-            M[k + NB * lane] = b; M[p + NB * lane] = a;
-        }
+        if (lane == 0) L.col[p] = make_double2(readlane_d(cx.x, K), readlane_d(cx.y, K));   // interchanged column K: row p carries the old M[K][K]
         wave_sync();
-        const double2 pv = M[k + NB * k];
-        const double den = pv.x * pv.x + pv.y * pv.y;
-        const double2 ip = make_double2(pv.x / den, -pv.y / den);
-        double2 f[6];                                            // multiplier M[i][k] of the row each of my elements sits in
+        if (mine) {                                              // row p takes the old row K (row K itself is rebuilt below)
 #pragma unroll
-        for (int m = 0; m < 6; ++m) { const int e = lane + 64 * m; f[m] = (e < BLK) ? M[(e % NB) + NB * k] : make_double2(0.0, 0.0); }
-        wave_sync();
-        if (lane < NB) {                                         // pivot row: (k,k) -> 1, then scale
-            const double2 x = (lane == k) ? make_double2(1.0, 0.0) : M[k + NB * lane];
-            M[k + NB * lane] = gmul(x, ip);
-        }
-        wave_sync();
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const int e = lane + 64 * m;
-            if (e < BLK) {
-                const int i = e % NB, j = e / NB;
-                if (i != k) {
-                    const double2 r = M[k + NB * j];
-                    const double2 x = (j == k) ? make_double2(0.0, 0.0) : M[e];
-                    const double2 t = gmul(f[m], r);
-                    M[e] = make_double2(x.x - t.x, x.y - t.y);
-                }
+            for (int c = 0; c < 3; ++c) {
+                const double2 x = L.rowk[3 * jg + c];
+                q[0][c] = sel(!odd, x, q[0][c]);
+                q[1][c] = sel(odd, x, q[1][c]);
             }
         }
-        wave_sync();
+        prow = L.rowp;
     }
-#pragma unroll 1
-    for (int k = NB - 1; k >= 0; --k) {                          // undo the row interchanges as column interchanges
-        const int p = piv[k];
-        if (p != k && lane < NB) {
-            const double2 a = M[lane + NB * k], b = M[lane + NB * p];
-            M[lane + NB * k] = b; M[lane + NB * p] = a;
+    double2 r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double2 rv = prow[3 * jg + c];
+        if (c == KC) rv = sel(in_col, make_double2(1.0, 0.0), rv);
+        r[c] = gmul(rv, ip);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        double2 f = L.col[2 * ig + rr];
+        if (rr == KR) f = sel(in_row, make_double2(-1.0, 0.0), f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double2 x = q[rr][c];
+            if (rr == KR && c == KC) x = sel(in_row || in_col, make_double2(0.0, 0.0), x);
+            else if (rr == KR) x = sel(in_row, make_double2(0.0, 0.0), x);
+            else if (c == KC) x = sel(in_col, make_double2(0.0, 0.0), x);
+            q[rr][c] = cfms(f, r[c], x);
         }
-        wave_sync();
+    }
+}
+template <int K>
+__device__ __forceinline__ void gauss_jordan_from(double2 (&q)[2][3], GreenLds& L, int lane, int ig, int jg, bool act) {
+    if constexpr (K < NB) {
+        gauss_jordan_step<K>(q, L, lane, ig, jg, act);
+        gauss_jordan_from<K + 1>(q, L, lane, ig, jg, act);
+    }
+}
+// undo the row interchanges of the elimination as column interchanges, last first
+template <int K>
+__device__ __forceinline__ void unpermute_from(double2 (&q)[2][3], GreenLds& L, int ig, int jg, bool act) {
+    if constexpr (K >= 0) {
+        constexpr int KC = K % 3, KJG = K / 3;
+        const int p = __builtin_amdgcn_readfirstlane(L.piv[K]);
+        if (p != K) {                                            // wave-uniform
+            const int pjg = p / 3, pc = p - 3 * pjg;
+            asm volatile("" : "+v"(jg));
+            if (act && jg == KJG) { L.rowk[2 * ig] = q[0][KC]; L.rowk[2 * ig + 1] = q[1][KC]; }
+            if (act && jg == pjg) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) L.rowp[2 * ig + rr] = sel(pc == 0, q[rr][0], sel(pc == 1, q[rr][1], q[rr][2]));
+            }
+            wave_sync();
+            if (act && jg == KJG) { q[0][KC] = L.rowp[2 * ig]; q[1][KC] = L.rowp[2 * ig + 1]; }
+            if (act && jg == pjg) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const double2 x = L.rowk[2 * ig + rr];
+                    q[rr][0] = sel(pc == 0, x, q[rr][0]); q[rr][1] = sel(pc == 1, x, q[rr][1]); q[rr][2] = sel(pc == 2, x, q[rr][2]);
+                }
+            }
+            wave_sync();
+        }
+        unpermute_from<K - 1>(q, L, ig, jg, act);
     }
 }
 
+// A_l block of this lane and the lane's share of B_l (staged to LDS at the start of the level that uses them)
+__device__ __forceinline__ void green_fetch(double2 (&an)[2][3], double2 (&bn)[6], const double2* __restrict__ A, const double2* __restrict__ Bl, int lane, int ig, int jg) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) an[rr][c] = A[(2 * ig + rr) + NB * (3 * jg + c)];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; bn[m] = Bl[el < BLK ? el : 0]; }
+}
+
 // grid = (ceil(nen / GREEN_WAVES), nsites).  a_b, b_sqrt: [site][lld][324] complex; a_inf, b_inf: [site][324] real; g0: [site][nen][324]
-__global__ __launch_bounds__(GREEN_WAVES * 64) void k_block_green(int lld, int nen, const double* __restrict__ ene, double eta_re, double eta_im, int sym_term,
+#ifndef GREEN_WAVES_PER_SIMD
+#define GREEN_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(GREEN_WAVES * 64, GREEN_WAVES_PER_SIMD) void k_block_green(int lld, int nen, const double* __restrict__ ene, double eta_re, double eta_im, int sym_term,
                                                                  const double* __restrict__ a_inf, const double* __restrict__ b_inf,
                                                                  const double2* __restrict__ a_b, const double2* __restrict__ b_sqrt, double2* __restrict__ g0) {
-    __shared__ double lds[GREEN_LDS_DOUBLES];
+    __shared__ GreenLds lds[GREEN_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ei = blockIdx.x * GREEN_WAVES + wave, site = blockIdx.y;
     if (ei >= nen) return;                                       // wave-uniform; no workgroup barriers below
-    double* mine = lds + (size_t)wave * (3 * 2 * BLK + 32);
-    double2* Q = reinterpret_cast<double2*>(mine);
-    double2* X = Q + BLK;
-    double2* B = X + BLK;
-    int* piv = reinterpret_cast<int*>(B + BLK);
+    GreenLds& L = lds[wave];
+    const bool act = lane < 54;                                  // lanes 54..63 shadow lane 53 and never store
+    const int ig = act ? lane / 6 : 8, jg = act ? lane % 6 : 5;
     const double e = ene[ei];
     const double* ai = a_inf + (size_t)site * BLK;
     const double* bi = b_inf + (size_t)site * BLK;
     const double a_diag = 0.5 * (ai[0] + ai[9 + NB * 9]), b_diag = 0.5 * (bi[0] + bi[9 + NB * 9]);
+    double2 q[2][3];
     // terminator (:1263-1289)
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        const int el = lane + 64 * m;
-        if (el < BLK) {
-            const int i = el % NB, j = el / NB;
-            double2 q = make_double2(0.0, 0.0);
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int i = 2 * ig + rr, j = 3 * jg + c;
+            double2 x = make_double2(0.0, 0.0);
             if (i == j) {
                 double etop, ebot, aref;
                 if (sym_term) { etop = a_diag + 2.0 * b_diag; ebot = a_diag - 2.0 * b_diag; aref = a_diag; }
@@ -122,66 +212,87 @@ __global__ __launch_bounds__(GREEN_WAVES * 64) void k_block_green(int lld, int n
                 }
                 const double det = (e - etop) * (e - ebot);
                 const double zr = det >= 0.0 ? sqrt(det) : 0.0, zi = det >= 0.0 ? 0.0 : sqrt(-det);
-                q = make_double2((e + eta_re - aref - zr) * 0.5, (eta_im - zi) * 0.5);
+                x = make_double2((e + eta_re - aref - zr) * 0.5, (eta_im - zi) * 0.5);
             }
-            Q[el] = q;
+            q[rr][c] = x;
         }
-    }
-    wave_sync();
     const double pr = e + (e != 0.0 ? eta_re : 0.0), pim = (e != 0.0 ? eta_im : 0.0);
+    // operands of a level are fetched one level ahead (they are shared by all energies of the site and L2-resident)
+    double2 an[2][3], bn[6];
+    if (lld > 1) green_fetch(an, bn, a_b + ((size_t)site * lld + (lld - 2)) * BLK, b_sqrt + ((size_t)site * lld + (lld - 2)) * BLK, lane, ig, jg);
 #pragma unroll 1
     for (int l = lld - 1; l >= 1; --l) {
-        const double2* A = a_b + ((size_t)site * lld + (l - 1)) * BLK;
-        const double2* Bl = b_sqrt + ((size_t)site * lld + (l - 1)) * BLK;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const int el = lane + 64 * m;
-            if (el < BLK) {
-                const int i = el % NB, j = el / NB;
-                const double2 a = A[el], q = Q[el];
-                Q[el] = make_double2((i == j ? pr : 0.0) - a.x - q.x, (i == j ? pim : 0.0) - a.y - q.y);
-                B[el] = Bl[el];
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool dg = (2 * ig + rr) == (3 * jg + c);
+                q[rr][c] = make_double2((dg ? pr : 0.0) - an[rr][c].x - q[rr][c].x, (dg ? pim : 0.0) - an[rr][c].y - q[rr][c].y);
+            }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) L.B[el] = bn[m]; }
+        if (l > 1) green_fetch(an, bn, a_b + ((size_t)site * lld + (l - 2)) * BLK, b_sqrt + ((size_t)site * lld + (l - 2)) * BLK, lane, ig, jg);
+        gauss_jordan_from<0>(q, L, lane, ig, jg, act);
+        unpermute_from<NB - 1>(q, L, ig, jg, act);
+        // X = Q^-1 B
+        if (act) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) L.M[(2 * ig + rr) + NB * (3 * jg + c)] = q[rr][c];
+        }
+        wave_sync();
+        double2 x[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[rr][c] = make_double2(0.0, 0.0);
+#pragma unroll 3
+        for (int k = 0; k < NB; ++k) {
+            const double2 m0 = L.M[2 * ig + NB * k], m1 = L.M[2 * ig + 1 + NB * k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double2 b = L.B[k + NB * (3 * jg + c)];
+                x[0][c] = cfma(m0, b, x[0][c]);
+                x[1][c] = cfma(m1, b, x[1][c]);
             }
         }
         wave_sync();
-        wave_inverse18(Q, piv, lane);
-        // X = Q B
+        if (act) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const int el = lane + 64 * m;
-            if (el < BLK) {
-                const int i = el % NB, j = el / NB;
-                double2 s = make_double2(0.0, 0.0);
-#pragma unroll 6
-                for (int k = 0; k < NB; ++k) {
-                    const double2 t = gmul(Q[i + NB * k], B[k + NB * j]);
-                    s.x += t.x; s.y += t.y;
-                }
-                X[el] = s;
-            }
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) L.M[(2 * ig + rr) + NB * (3 * jg + c)] = x[rr][c];
         }
         wave_sync();
         // Q = B^H X
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const int el = lane + 64 * m;
-            if (el < BLK) {
-                const int i = el % NB, j = el / NB;
-                double2 s = make_double2(0.0, 0.0);
-#pragma unroll 6
-                for (int k = 0; k < NB; ++k) {
-                    const double2 b = B[k + NB * i], x = X[k + NB * j];
-                    s.x += b.x * x.x + b.y * x.y;
-                    s.y += b.x * x.y - b.y * x.x;
-                }
-                Q[el] = s;
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[rr][c] = make_double2(0.0, 0.0);
+#pragma unroll 3
+        for (int k = 0; k < NB; ++k) {
+            const double2 b0 = L.B[k + NB * (2 * ig)], b1 = L.B[k + NB * (2 * ig + 1)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double2 xv = L.M[k + NB * (3 * jg + c)];
+                q[0][c] = cfmah(b0, xv, q[0][c]);
+                q[1][c] = cfmah(b1, xv, q[1][c]);
             }
         }
         wave_sync();
     }
+    // coalesced store through the staging matrix
+    if (act) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L.M[(2 * ig + rr) + NB * (3 * jg + c)] = q[rr][c];
+    }
+    wave_sync();
     double2* out = g0 + ((size_t)site * nen + ei) * BLK;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) out[el] = Q[el]; }
+    for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) out[el] = L.M[el]; }
 }
 
 // green%chebyshev_green (green.f90:1030-1108): g0(:,:,ie) = sum_i mu_ng(:,:,i) (-i exp(-i (i-1) acos w_ie)) / sqrt(a^2 - (e_ie - b)^2),
