@@ -59,6 +59,12 @@ __device__ __forceinline__ double dpp_d(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xf, 0xf, false));
+}
+
 // One Gauss-Jordan step (column K, a compile-time constant: every register index below is static) of the in-place inverse with
 // partial pivoting.  Row interchange k <-> p, then  M'[i][j] = x[i][j] - f_i r_j  with  r = (row k with M[k][k] := 1) / pivot,
 // f = column k with f_k := -1, x = M with row k and column k zeroed.  Row K sits in register row K & 1 of the lanes ig == K >> 1,
@@ -78,16 +84,29 @@ __device__ __forceinline__ void gauss_jordan_step(double2 (&q)[2][3], GreenLds& 
     double2 cx = make_double2(0.0, 0.0);
     double v = -1.0;
     if (lane < NB) { cx = L.col[lane]; if (lane >= K) v = fabs(cx.x) + fabs(cx.y); }
-    double m = fmax(v, dpp_d<0x111>(v));
-    m = fmax(m, dpp_d<0x112>(m));
-    m = fmax(m, dpp_d<0x114>(m));
-    m = fmax(m, dpp_d<0x118>(m));
-    const double vmax = fmax(readlane_d(m, 15), readlane_d(m, 31));
-    const unsigned long long hit = __ballot(v == vmax);
+    // single-precision keys decide unless two candidates round to the same float; then the exact comparison does
+    const float kf = (float)v;
+    float mf = fmaxf(kf, dpp_f<0x111>(kf));
+    mf = fmaxf(mf, dpp_f<0x112>(mf));
+    mf = fmaxf(mf, dpp_f<0x114>(mf));
+    mf = fmaxf(mf, dpp_f<0x118>(mf));
+    const float vmaxf = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mf), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mf), 31)));
+    unsigned long long hit = __ballot(kf == vmaxf);
+    if (__builtin_popcountll(hit) != 1) {                        // wave-uniform, rare
+        double m = fmax(v, dpp_d<0x111>(v));
+        m = fmax(m, dpp_d<0x112>(m));
+        m = fmax(m, dpp_d<0x114>(m));
+        m = fmax(m, dpp_d<0x118>(m));
+        const double vmax = fmax(readlane_d(m, 15), readlane_d(m, 31));
+        hit = __ballot(v == vmax);
+    }
     const int p = hit ? (int)__builtin_ctzll(hit) : K;
     if (lane == 0) L.piv[K] = p;
     const double2 pv = make_double2(readlane_d(cx.x, p), readlane_d(cx.y, p));      // pivot = M[p][K]
-    const double rden = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+    const double den = pv.x * pv.x + pv.y * pv.y;
+    double rden = __builtin_amdgcn_rcp(den);                     // two Newton steps on the hardware estimate: full double precision
+    rden = fma(rden, fma(-den, rden, 1.0), rden);
+    rden = fma(rden, fma(-den, rden, 1.0), rden);
     const double2 ip = make_double2(pv.x * rden, -pv.y * rden);
     const double2* prow = L.rowk;
     if (p != K) {                                                // wave-uniform: rows K and p change places

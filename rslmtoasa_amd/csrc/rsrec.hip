@@ -52,6 +52,8 @@ struct DevBuf {
 struct rsrec_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // device -> host copies of the Green stage, overlapped with its kernels
+    hipEvent_t ev_green[2] = {nullptr, nullptr};
     std::string err;
     // lattice (host copies for the region search + device tables)
     bool have_lattice = false, have_ham = false;
@@ -301,6 +303,8 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     h->s5_op.release();
     if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (hipEvent_t e : h->ev_green) if (e) (void)hipEventDestroy(e);
     delete h;
     return RSREC_OK;
 }
@@ -1003,6 +1007,48 @@ extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
     return RSREC_OK;
 }
 
+namespace {
+
+// The Green stage produces far more than it consumes (13 MB of g0 per site for 2510 energies): the sites are cut into chunks,
+// chunk c + 1 is computed on h->stream while chunk c leaves the device on h->copy_stream (two output buffers).  The caller's
+// array is pageable, so the copy blocks the host -- after the next kernel has been queued.
+// launch(s0, ns, out): queue the kernel for sites s0 .. s0 + ns - 1 of the call, writing ns * gbytes bytes at `out`.
+template <class Launch>
+int green_pipeline(rsrec_t* h, int nsites, size_t gbytes, double* g0, Launch launch) {
+    if (!h->copy_stream) HIPCK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->ev_green)
+        if (!e) HIPCK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const size_t cap = ((size_t)1 << 29) / gbytes;                                  // <= 2 x 512 MiB of g0 on the device
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(cap, ((size_t)nsites + 7) / 8));
+    HIPCK(h, h->d_green_out.reserve(2 * (size_t)chunk * gbytes));
+    char* out[2] = {static_cast<char*>(h->d_green_out.p), static_cast<char*>(h->d_green_out.p) + (size_t)chunk * gbytes};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    auto drain = [&](int s0, int ns, int b) -> int {
+        HIPCK(h, hipStreamWaitEvent(h->copy_stream, h->ev_green[b], 0));
+        HIPCK(h, hipMemcpyAsync(reinterpret_cast<char*>(g0) + (size_t)s0 * gbytes, out[b], (size_t)ns * gbytes, hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCK(h, hipStreamSynchronize(h->copy_stream));
+        return RSREC_OK;
+    };
+    int prev_s0 = -1, prev_ns = 0, c = 0;
+    for (int s0 = 0; s0 < nsites; s0 += chunk, ++c) {
+        const int ns = std::min(chunk, nsites - s0);
+        hipEvent_t k0 = next_event(h);
+        launch(s0, ns, out[c & 1]);
+        hipEvent_t k1 = next_event(h);
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipEventRecord(h->ev_green[c & 1], h->stream));
+        spans.emplace_back(k0, k1);
+        if (prev_s0 >= 0) XFER(drain(prev_s0, prev_ns, (c - 1) & 1));               // buffer (c - 1) & 1 is free again before kernel c + 1 is queued
+        prev_s0 = s0; prev_ns = ns;
+    }
+    if (prev_s0 >= 0) XFER(drain(prev_s0, prev_ns, (c - 1) & 1));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    for (auto& sp : spans) h->t_hop_ms += ev_ms(sp.first, sp.second);              // "hop_ms": the Green kernels themselves; total_ms includes the transfers
+    return RSREC_OK;
+}
+
+}  // namespace
+
 // green%block_green / bgreen (green.f90:588-621, :1191-1339): g0(:,:,:,site) from the block coefficients of every site.
 extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const double* ene, double eta_re, double eta_im, int sym_term,
                                  const double* a_inf, const double* b_inf, const double* a_b, const double* b_sqrt, double* g0) {
@@ -1014,32 +1060,29 @@ extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const
     const size_t cbytes = (size_t)lld * BLK * sizeof(double2);       // coefficients of one site (each of a_b, b_sqrt)
     const size_t tbytes = (size_t)BLK * sizeof(double);              // terminator of one site (each of a_inf, b_inf)
     const size_t gbytes = (size_t)nen * BLK * sizeof(double2);       // g0 of one site
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)1 << 30) / gbytes));   // <= 1 GiB of g0 on the device at a time
-    HIPCK(h, h->d_green_in.reserve((size_t)chunk * (2 * cbytes + 2 * tbytes) + (size_t)nen * sizeof(double)));
-    HIPCK(h, h->d_green_out.reserve((size_t)chunk * gbytes));
+    const size_t in_site = 2 * cbytes + 2 * tbytes;
+    const int super = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)4 << 30) / in_site));   // <= 4 GiB of coefficients resident
+    HIPCK(h, h->d_green_in.reserve((size_t)super * in_site + (size_t)nen * sizeof(double)));
     char* base = static_cast<char*>(h->d_green_in.p);
     double* d_ene = reinterpret_cast<double*>(base);
     double2* d_ab = reinterpret_cast<double2*>(base + (size_t)nen * sizeof(double));
-    double2* d_bs = reinterpret_cast<double2*>(reinterpret_cast<char*>(d_ab) + (size_t)chunk * cbytes);
-    double* d_ai = reinterpret_cast<double*>(reinterpret_cast<char*>(d_bs) + (size_t)chunk * cbytes);
-    double* d_bi = reinterpret_cast<double*>(reinterpret_cast<char*>(d_ai) + (size_t)chunk * tbytes);
+    double2* d_bs = reinterpret_cast<double2*>(reinterpret_cast<char*>(d_ab) + (size_t)super * cbytes);
+    double* d_ai = reinterpret_cast<double*>(reinterpret_cast<char*>(d_bs) + (size_t)super * cbytes);
+    double* d_bi = reinterpret_cast<double*>(reinterpret_cast<char*>(d_ai) + (size_t)super * tbytes);
     XFER(xfer_h2d(h, d_ene, ene, (size_t)nen * sizeof(double)));
     reset_timing(h);
     hipEvent_t ev0 = next_event(h);
-    for (int s0 = 0; s0 < nsites; s0 += chunk) {
-        const int ns = std::min(chunk, nsites - s0);
-        XFER(xfer_h2d(h, d_ab, a_b + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes));
-        XFER(xfer_h2d(h, d_bs, b_sqrt + (size_t)s0 * lld * BLK * 2, (size_t)ns * cbytes));
-        XFER(xfer_h2d(h, d_ai, a_inf + (size_t)s0 * BLK, (size_t)ns * tbytes));
-        XFER(xfer_h2d(h, d_bi, b_inf + (size_t)s0 * BLK, (size_t)ns * tbytes));
-        const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, ns);
-        hipEvent_t k0 = next_event(h);
-        k_block_green<<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai, d_bi, d_ab, d_bs, h->d_green_out.as<double2>());
-        hipEvent_t k1 = next_event(h);
-        HIPCK(h, hipGetLastError());
-        XFER(xfer_d2h(h, g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes));
-        HIPCK(h, hipStreamSynchronize(h->stream));
-        h->t_hop_ms += ev_ms(k0, k1);          // reported as "hop_ms": the Green kernel itself; total_ms includes the transfers
+    for (int u0 = 0; u0 < nsites; u0 += super) {
+        const int nu = std::min(super, nsites - u0);
+        XFER(xfer_h2d(h, d_ab, a_b + (size_t)u0 * lld * BLK * 2, (size_t)nu * cbytes));
+        XFER(xfer_h2d(h, d_bs, b_sqrt + (size_t)u0 * lld * BLK * 2, (size_t)nu * cbytes));
+        XFER(xfer_h2d(h, d_ai, a_inf + (size_t)u0 * BLK, (size_t)nu * tbytes));
+        XFER(xfer_h2d(h, d_bi, b_inf + (size_t)u0 * BLK, (size_t)nu * tbytes));
+        XFER(green_pipeline(h, nu, gbytes, g0 + (size_t)u0 * nen * BLK * 2, [&](int s0, int ns, char* out) {
+            const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, ns);
+            k_block_green<<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai + (size_t)s0 * BLK, d_bi + (size_t)s0 * BLK,
+                                                                    d_ab + (size_t)s0 * lld * BLK, d_bs + (size_t)s0 * lld * BLK, reinterpret_cast<double2*>(out));
+        }));
     }
     hipEvent_t ev1 = next_event(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -1068,23 +1111,25 @@ extern "C" int rsrec_chebyshev_green(rsrec_t* h, int nsites, int lld, int nen, c
         }
     }
     const size_t mbytes = (size_t)nm * BLK * sizeof(double2), gbytes = (size_t)nen * BLK * sizeof(double2);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)1 << 30) / gbytes));
-    HIPCK(h, h->d_green_in.reserve((size_t)chunk * mbytes + (size_t)(nen + nm) * sizeof(double)));
-    HIPCK(h, h->d_green_out.reserve((size_t)chunk * gbytes));
+    const int super = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsites, ((size_t)4 << 30) / mbytes));
+    HIPCK(h, h->d_green_in.reserve((size_t)super * mbytes + (size_t)(nen + nm) * sizeof(double)));
     double* d_ene = static_cast<double*>(h->d_green_in.p);
     double* d_kern = d_ene + nen;
     double2* d_mu = reinterpret_cast<double2*>(d_kern + nm);
     XFER(xfer_h2d(h, d_ene, ene, (size_t)nen * sizeof(double)));
     XFER(xfer_h2d(h, d_kern, kern.data(), (size_t)nm * sizeof(double)));
-    HIPCK(h, hipStreamSynchronize(h->stream));              // kern is a stack-local vector
-    for (int s0 = 0; s0 < nsites; s0 += chunk) {
-        const int ns = std::min(chunk, nsites - s0);
-        XFER(xfer_h2d(h, d_mu, mu_n + (size_t)s0 * nm * BLK * 2, (size_t)ns * mbytes));
-        k_chebyshev_green<<<dim3(nen, ns), 256, (size_t)nm * sizeof(double2), h->stream>>>(nm, nen, d_ene, a, b, d_kern, d_mu, h->d_green_out.as<double2>());
-        HIPCK(h, hipGetLastError());
-        XFER(xfer_d2h(h, g0 + (size_t)s0 * nen * BLK * 2, h->d_green_out.p, (size_t)ns * gbytes));
-        HIPCK(h, hipStreamSynchronize(h->stream));
+    reset_timing(h);
+    hipEvent_t ev0 = next_event(h);
+    for (int u0 = 0; u0 < nsites; u0 += super) {
+        const int nu = std::min(super, nsites - u0);
+        XFER(xfer_h2d(h, d_mu, mu_n + (size_t)u0 * nm * BLK * 2, (size_t)nu * mbytes));
+        XFER(green_pipeline(h, nu, gbytes, g0 + (size_t)u0 * nen * BLK * 2, [&](int s0, int ns, char* out) {
+            k_chebyshev_green<<<dim3(nen, ns), 256, (size_t)nm * sizeof(double2), h->stream>>>(nm, nen, d_ene, a, b, d_kern, d_mu + (size_t)s0 * nm * BLK, reinterpret_cast<double2*>(out));
+        }));
     }
+    hipEvent_t ev1 = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(ev0, ev1);
     return RSREC_OK;
 }
 

@@ -18,7 +18,13 @@ class Green:
         self.recursion = recursion
         self.ene = np.ascontiguousarray(ene, dtype=np.float64)      # energy%ene(1:channels_ldos+10), energy.f90:205-207
         self.sym_term = bool(sym_term)                              # control%sym_term
-        self.g0 = None
+        self.g0 = None                                              # green%g0: allocated once, overwritten by every call (green.f90:150-170)
+
+    def _g0_buffer(self, n):
+        shape = (18, 18, len(self.ene), n)
+        if self.g0 is None or self.g0.shape != shape:
+            self.g0 = np.zeros(shape, dtype=np.complex128, order="F")
+        return self.g0
 
     def block_green(self, a_inf, b_inf, eta=0.0 + 0.0j, nsites=None):
         """green%block_green: requires ``recursion.zsqr()`` to have been called (self.f90:829), like the reference."""
@@ -30,10 +36,9 @@ class Green:
         a_inf = np.asfortranarray(a_inf, dtype=np.float64)
         b_inf = np.asfortranarray(b_inf, dtype=np.float64)
         assert a_inf.shape == (18, 18, n) and b_inf.shape == (18, 18, n)
-        g0 = np.zeros((18, 18, len(self.ene), n), dtype=np.complex128, order="F")
+        g0 = self._g0_buffer(n)
         rec._check(rec._L.rsrec_block_green(rec._h, n, lld, len(self.ene), _ptr(self.ene), float(np.real(eta)), float(np.imag(eta)),
                                             int(self.sym_term), _ptr(a_inf), _ptr(b_inf), _ptr(a_b), _ptr(b_s), _ptr(g0)))
-        self.g0 = g0
         return g0
 
     def chebyshev_green(self, nsites=None):
@@ -42,10 +47,9 @@ class Green:
         n = rec.mu_n.shape[3] if nsites is None else nsites
         lld = (rec.mu_n.shape[2] - 2) // 2
         mu = np.asfortranarray(rec.mu_n[:, :, :, :n])
-        g0 = np.zeros((18, 18, len(self.ene), n), dtype=np.complex128, order="F")
+        g0 = self._g0_buffer(n)
         rec._check(rec._L.rsrec_chebyshev_green(rec._h, n, lld, len(self.ene), _ptr(self.ene), float(rec.en.energy_min), float(rec.en.energy_max),
                                                 _ptr(mu), _ptr(g0)))
-        self.g0 = g0
         return g0
 
     def ldos(self):
