@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Timing of the Chebyshev Green-function stage at BASELINE config-1 size: 64 sites x 2510 energies x LL=50 (rsrec_chebyshev_green)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import objects_from, supercell_problem
+from rslmtoasa_amd.green import Green
+from rslmtoasa_amd.lattice import spread_sites
+from rslmtoasa_amd.recursion import Recursion
+
+if __name__ == "__main__":
+    nsites, lld, nen = 64, 50, 2510
+    p = supercell_problem((22, 22, 22))
+    rec = Recursion(*objects_from(p, spread_sites(p["nn"].shape[0], nsites), lld, emin=-3.0, emax=1.8))
+    rec.chebyshev_recur()
+    t_rec = rec.timing()["total_ms"]
+    ene = np.linspace(-1.0, 0.6, nen)
+    gr = Green(rec, ene)
+    for _ in range(2):
+        t0 = time.time(); gr.chebyshev_green(); wall = time.time() - t0
+        tm = rec.timing()
+    print("chebyshev recursion %.1f ms | chebyshev_green: kernels %.1f ms, with transfers %.1f ms, wall %.1f ms (g0 = %.0f MB)" % (
+        t_rec, tm["hop_ms"], tm["total_ms"], wall * 1e3, gr.g0.nbytes / 1e6))
+    from oracle import oracle
+    sel = np.array([0, 1, 1255, 2509])
+    ref = oracle.chebyshev_green(np.asfortranarray(rec.mu_n[:, :, :, 63]), ene[sel], -3.0, 1.8)
+    print("max |gpu - oracle| over 4 energies of site 63: %.3e (|g0| max %.3e)" % (np.abs(gr.g0[:, :, sel, 63] - ref).max(), np.abs(ref).max()))
+    rec.close()
