@@ -372,16 +372,20 @@ __global__ __launch_bounds__(1024) void k_reduce_cheb_mf(const double* __restric
 // 36x36 Gram partials of up to 256 workgroups per chain (2.6 MB) were summed by ONE workgroup per chain in the reduce kernels:
 // at a single chain that is one CU's L2 bandwidth, 40-100 us per level and half of the single-site recursion.  Fixed grouping
 // (16) and fixed order keep the result independent of launch width and batch composition (trailing all-zero partials add +0).
-__global__ __launch_bounds__(256) void k_presum16(const double* __restrict__ in, int nblk, int width, double* __restrict__ out) {
-    const int b = blockIdx.x, chain = blockIdx.y, nblk2 = gridDim.x;
+// grid = (nblk2 * ceil(width / 256), chains): one output element per thread, its 16 addends in flight together
+__global__ __launch_bounds__(256) void k_presum16(const double* __restrict__ in, int nblk, int nblk2, int width, double* __restrict__ out) {
+    const int nchunk = (width + 255) >> 8;
+    const int b = blockIdx.x / nchunk, e = (blockIdx.x % nchunk) * 256 + threadIdx.x, chain = blockIdx.y;
+    if (e >= width) return;
     const int p0 = 16 * b, p1 = min(nblk, p0 + 16);
-    const double* src = in + (size_t)chain * nblk * width;
-    double* dst = out + ((size_t)chain * nblk2 + b) * width;
-    for (int e = threadIdx.x; e < width; e += blockDim.x) {
-        double s = 0.0;
-        for (int p = p0; p < p1; ++p) s += src[(size_t)p * width + e];
-        dst[e] = s;
-    }
+    const double* src = in + (size_t)chain * nblk * width + e;
+    double v[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p] = (p0 + p < p1) ? src[(size_t)(p0 + p) * width] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s += v[p];                  // fixed order; missing trailing partials add +0
+    out[((size_t)chain * nblk2 + b) * width + e] = s;
 }
 
 }  // namespace rsrec

@@ -54,6 +54,9 @@ struct rsrec_handle {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;     // device -> host copies of the Green stage, overlapped with its kernels
     hipEvent_t ev_green[2] = {nullptr, nullptr};
+    hipStream_t side_stream = nullptr;     // B_{n+1} reduction + eigen-solve of level n, concurrent with H u_{n+1} of level n + 1 (u-scheme)
+    hipEvent_t ev_orth = nullptr, ev_bred = nullptr;
+    size_t p2_slot = 0;                    // doubles per slot of d_partial2 (slot 1: the side stream's presum)
     std::string err;
     // lattice (host copies for the region search + device tables)
     bool have_lattice = false, have_ham = false;
@@ -76,7 +79,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_kp_only = 0;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_kp_only = 0, opt_side = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -305,6 +308,9 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (hipEvent_t e : h->ev_green) if (e) (void)hipEventDestroy(e);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_orth) (void)hipEventDestroy(h->ev_orth);
+    if (h->ev_bred) (void)hipEventDestroy(h->ev_bred);
     delete h;
     return RSREC_OK;
 }
@@ -328,6 +334,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "kp_only")) h->opt_kp_only = value;
+    else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -698,13 +705,18 @@ dim3 s5_grid(const rsrec_t* h, dim3 full, int level) {
 }
 
 // Two-stage reduction of per-workgroup partials (k_presum16): returns the buffer and count the final reduce kernel reads.
-const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int width) {
+const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int width, hipStream_t stream = nullptr, int slot = 0) {
     if (nblk <= 32) return partial;
     const int nblk2 = (nblk + 15) / 16;
-    if (h->d_partial2.reserve((size_t)nb * nblk2 * width * sizeof(double)) != hipSuccess) return partial;   // fall back to the single-stage sum
-    k_presum16<<<dim3(nblk2, nb), 256, 0, h->stream>>>(partial, nblk, width, h->d_partial2.as<double>());
+    const size_t need = (size_t)nb * nblk2 * width;
+    if (slot == 0 && h->p2_slot == 0) {
+        if (h->d_partial2.reserve(need * sizeof(double)) != hipSuccess) return partial;     // fall back to the single-stage sum
+    } else if (need > h->p2_slot) return partial;
+    double* out = h->d_partial2.as<double>() + (size_t)slot * h->p2_slot;
+    const int nchunk = (width + 255) / 256;
+    k_presum16<<<dim3(nblk2 * nchunk, nb), 256, 0, stream ? stream : h->stream>>>(partial, nblk, nblk2, width, out);
     nblk = nblk2;
-    return h->d_partial2.as<double>();
+    return out;
 }
 
 // store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
@@ -758,8 +770,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
-    HIPCK(h, h->d_partial.reserve((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2)));
-    HIPCK(h, h->d_partial2.reserve((size_t)B * 16 * 2 * 1296 * sizeof(double)));      // second stage of the partial sums (presum): sized once, never grown mid-stream
+    const size_t gram_elems = (size_t)B * 256 * 1296;                                  // doubles: Gram partials of one kernel (<= 256 workgroups per chain)
+    HIPCK(h, h->d_partial.reserve(std::max((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2), 2 * gram_elems * sizeof(double))));
+    h->p2_slot = (size_t)B * 16 * 2 * 1296;
+    HIPCK(h, h->d_partial2.reserve(2 * h->p2_slot * sizeof(double)));                  // second stage of the partial sums (presum), two slots: sized once, never grown mid-stream
+    if (!h->side_stream) {
+        HIPCK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIPCK(h, hipEventCreateWithFlags(&h->ev_orth, hipEventDisableTiming));
+        HIPCK(h, hipEventCreateWithFlags(&h->ev_bred, hipEventDisableTiming));
+    }
     HIPCK(h, h->d_frags.reserve((size_t)B * 4 * 27 * 64 * sizeof(double)));
     HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
@@ -776,6 +795,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     double2* dB = h->d_coefB.as<double2>();
     double2* partial = h->d_partial.as<double2>();
     double* gpartial = h->d_partial.as<double>();
+    double* gpartial_b = gpartial + gram_elems;          // Gram partials of k_mfma_orth3 when their reduction runs on the side stream
     double* afrags = h->d_frags.as<double>();
     double* bfrags = afrags + (size_t)B * 27 * 64;
     const bool mf_post = MFMA && h->opt_post != 1;
@@ -824,6 +844,29 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         if (kp_only) psi = ukp;
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+        // u-scheme: H u_{n+1} does not need B_{n+1}, so the reduction of sum u_{n+1}^H u_{n+1} and its 18x18 eigen-solve (one
+        // workgroup per chain, 80 us) leave the critical path: they run on the side stream while the main stream already applies H.
+        // The main stream waits for them before k_reduce_a_u of the next level (first consumer of Binv_{n+1}).
+        const bool side = h->opt_side && h->side_stream;
+        double* gp_b = side ? gpartial_b : gpartial;
+        bool b_pending = false;
+        auto wait_b_level = [&]() -> int {
+            if (b_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); b_pending = false; }
+            return RSREC_OK;
+        };
+        auto reduce_b_level = [&](int nwg, int ll) -> int {
+            hipStream_t st = h->stream;
+            if (side) {
+                HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
+                HIPCK(h, hipStreamWaitEvent(h->side_stream, h->ev_orth, 0));
+                st = h->side_stream;
+            }
+            int n2 = nwg;
+            const double* p2 = presum(h, gp_b, nb, n2, 1296, st, side ? 1 : 0);
+            k_reduce_b_u<<<nb, 1024, 0, st>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags, h->d_status.as<int>());
+            if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); b_pending = true; }
+            return RSREC_OK;
+        };
         for (int ll = 0; ll < nsteps; ++ll) {
             const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
             const double* tvec = nullptr;                      // H psi when it is held in a vector of its own
@@ -861,13 +904,12 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                             else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                             { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                              rc = wait_b_level(); if (rc) return rc;
                               k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                            if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
-                            else if (use_kp) k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                            else k_mfma_orth3<0><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
-                            { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
-                              k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                        h->d_status.as<int>()); }
+                            if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                            else if (use_kp) k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b, ukp);
+                            else k_mfma_orth3<0><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                            rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                             std::swap(psi, t2);
                             hop_ev.emplace_back(e0, e1);
                             h->n_hop_launch += 1;
@@ -909,12 +951,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                  rc = wait_b_level(); if (rc) return rc;
                   k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial);
-                else k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gpartial, ukp);
-                { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
-                  k_reduce_b_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                            h->d_status.as<int>()); }
+                if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                else k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b, ukp);
+                rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                 std::swap(psi, t2);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += 2;
@@ -951,6 +992,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             k_update<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
         }
         HIPCK(h, hipGetLastError());
+        rc = wait_b_level(); if (rc) return rc;
         XFER(xfer_d2h(h, a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2)));
         XFER(xfer_d2h(h, b2_b + (size_t)c0 * cstride * 2, dB, (size_t)nb * cstride * sizeof(double2)));
         HIPCK(h, hipStreamSynchronize(h->stream));
@@ -1158,7 +1200,8 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const int B = bp.batch, nblk = bp.nblk;
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve(std::max((size_t)B * nblk * 2 * BLK * sizeof(double2), (size_t)B * 256 * 2 * 1296 * sizeof(double))));
-    HIPCK(h, h->d_partial2.reserve((size_t)B * 16 * 2 * 1296 * sizeof(double)));
+    h->p2_slot = (size_t)B * 16 * 2 * 1296;
+    HIPCK(h, h->d_partial2.reserve(h->p2_slot * sizeof(double)));
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
