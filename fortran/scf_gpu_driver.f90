@@ -14,6 +14,7 @@ program scf_gpu_driver
    use mpi_mod
    use control_mod
    use lattice_mod
+   use lattice_cells_mod
    use charge_mod
    use mix_mod
    use energy_mod
@@ -31,7 +32,7 @@ program scf_gpu_driver
 
    type(calculation) :: calc_obj
    type(control), target :: control_obj
-   type(lattice), target :: lattice_obj
+   type(lattice_cells), target :: lattice_obj   ! <-- third drop-in: O(N) neighbour search behind structb / newclu (CPU)
    type(energy), target :: energy_obj
    type(self), target :: self_obj
    type(charge), target :: charge_obj
@@ -51,7 +52,7 @@ program scf_gpu_driver
    calc_obj = calculation('input.nml')
    pre = trim(calc_obj%pre_processing)
    control_obj = control('input.nml')
-   lattice_obj = lattice(control_obj)
+   lattice_obj%lattice = lattice(control_obj)
    call g_timer%start('pre-processing')
    call lattice_obj%build_data()
    call lattice_obj%bravais()
@@ -73,7 +74,7 @@ program scf_gpu_driver
    end select
    call lattice_obj%atomlist()
    call get_mpi_variables(rank, lattice_obj%nrec)
-   charge_obj = charge(lattice_obj)
+   charge_obj = charge(lattice_obj%lattice)      ! (the constructors take a non-polymorphic type(lattice) dummy)
    select case (trim(pre))
    case ('bravais')
       call charge_obj%bulkmat()
@@ -86,8 +87,8 @@ program scf_gpu_driver
    end select
    call g_timer%stop('pre-processing')
 
-   mix_obj = mix(lattice_obj, charge_obj)
-   energy_obj = energy(lattice_obj)
+   mix_obj = mix(lattice_obj%lattice, charge_obj)
+   energy_obj = energy(lattice_obj%lattice)
    hamiltonian_obj = hamiltonian(charge_obj)
    recursion_obj = recursion_gpu(hamiltonian_obj, energy_obj)     ! <-- the one-line change
    dos_obj = dos(recursion_obj, energy_obj)

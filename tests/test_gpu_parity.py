@@ -199,6 +199,22 @@ def test_batching_is_invisible():
     rec.close()
 
 
+@pytest.mark.parametrize("hoh", [False, True])
+def test_side_stream_is_invisible(hoh):
+    """The B_{n+1} reduction / eigen-solve on the side stream (overlapped with the next H|u>) changes scheduling only: the
+    coefficients are bit-identical with the option off, on a launch wide enough for the two-stage partial sums (11^3 cell)."""
+    p = supercell_problem((11, 11, 11), hoh=hoh)
+    sites = np.array([1, 700, 1331], dtype=np.int32)
+    rec = Recursion(*objects_from(p, sites, 12))
+    rec.recur_b()
+    a1, b1 = rec.a_b.copy(), rec.b2_b.copy()
+    rec.set_option("side_stream", 0)
+    rec.recur_b()
+    assert np.array_equal(a1, rec.a_b) and np.array_equal(b1, rec.b2_b)
+    assert np.isfinite(a1).all() and np.abs(b1[:, :, 1:, :]).max() > 0.0
+    rec.close()
+
+
 @pytest.mark.parametrize("kernels", BLOCK_VARIANTS)
 @pytest.mark.parametrize("name", PAIR_CASES)
 def test_pair_variants_golden(name, kernels):
