@@ -64,12 +64,13 @@ def test_recursion_zsqr_green_pipeline(name):
     rec.close()
 
 
-def test_block_green_properties_full_mesh():
-    """Full 2510-point mesh, many sites: eta > 0 makes g analytic -> -Im g_jj > 0 everywhere; identical sites give identical g."""
+@pytest.mark.parametrize("nrep", [8, 11])
+def test_block_green_properties_full_mesh(nrep):
+    """Full 2510-point mesh, many sites: eta > 0 makes g analytic -> -Im g_jj > 0 everywhere; identical sites give identical g.
+    (8 sites: eight one-site chunks of the kernel / download pipeline; 11 sites: chunks of two with a ragged last one.)"""
     z = load_green("bccFe_nsp2_block")
     g = load_golden("bccFe_nsp2_block")
     rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
-    nrep = 8
     rec.a_b = np.asfortranarray(np.repeat(z["a_b"][:, :, :, :1], nrep, axis=3))
     rec.b2_b = np.asfortranarray(np.repeat(z["b_sqrt"][:, :, :, :1], nrep, axis=3))
     ene = float(z["ene_full_first"]) + float(z["ene_full_step"]) * np.arange(int(z["nen_full"]))
