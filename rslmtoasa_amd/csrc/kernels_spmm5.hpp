@@ -38,7 +38,7 @@ namespace rsrec {
                          //   5 = different s_setprio for the two spin waves (+0.7 %);  S5_WG_GROUPS = 2 (256-thread workgroups): +15 %
 #endif
 #ifndef S5_PROBE
-#define S5_PROBE 0   // timing probes only: 1 = no operator-fragment loads in the slot loop, 2 = no psi loads (results wrong)
+#define S5_PROBE 0   // timing probes only (results wrong): bit 0 = no operator-fragment loads in the slot loop, bit 1 = no psi loads, bit 2 = schedule walked twice
 #endif
 constexpr int S5_FRAG_PER_RB = 320;                         // doubles: pair 0 (128), pair 1 (128), single (64)
 constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][sigma_in][rb]
@@ -220,7 +220,8 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
                                              int nslots, int sig,
                                              unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
-    const int nmine = share[0];
+    const int n0 = share[0];
+    const int nmine = (S5_PROBE & 4) ? 2 * n0 : n0;           // probe 4: the schedule is walked twice (fixed per-group cost = 2 T(1x) - T(2x))
     if (nmine <= 0) return;
     const int nstride = nslots + 1;
     // neighbour indices: wave-uniform scalar loads for the 8 atom tiles, one per-lane load for the remainder tile; both are
@@ -243,7 +244,7 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     S5Slot cur;
     int nraw[GROUP], nrem;
     int e_cur = share[1];
-    int e_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
+    int e_nxt = share[1 + ((1 < nmine) ? 1 % n0 : 0)];
     load_idx(e_cur & 255, nraw, nrem);
     make_slot(nraw, nrem, cur, e_cur & 255);
     S5Pair X, Y;
@@ -252,7 +253,7 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
     if (S5_VARIANT == 5) { if (sig) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
     for (int j = 0; j < nmine; ++j) {
-        const int e_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last entry prefetches the first again (discarded)
+        const int e_nxt2 = share[1 + ((j + 2 < nmine) ? ((S5_PROBE & 4) ? (j + 2) % n0 : j + 2) : 0)];   // the last entry prefetches the first again (discarded)
         load_idx(e_nxt & 255, nraw, nrem);
         // (pinning the 32-bit lane offsets inside the loop makes hipcc emit SGPR-base + VGPR-offset loads, but costs 10 more VGPRs
         //  -> scratch spills in the group prologue and a 3.5 % slower kernel; measured, not used)
