@@ -282,7 +282,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
     GramAcc A;
     A.zero();
     const int nbx = active_workgroups(ngroups);
-    for (GroupWalk w(blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
+    for (GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
 #pragma unroll 4
         for (int kq = 0; kq < 36; ++kq) {

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     GramAcc Gm;
     Gm.zero();
     const int nbx = active_workgroups(ngroups);
-    GroupWalk w(blockIdx.x < nbx ? ngroups : 0, wave, nbx);
+    GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx);
     // row tiles of this wave, flattened: tile it = (group w.g + (it / 9) * step, rows 16 (it % 9) .. +15).  The operands of
     // tiles it + 1 and it + 2 are in flight while tile it is multiplied (one 512-register wave per SIMD: the reads in
     // flight are what hides the HBM latency, ~27 KB per wave)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
     GramAcc G1, G2;
     G1.zero(); G2.zero();
     const int nbx = active_workgroups(ngroups);
-    for (GroupWalk w(blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
+    for (GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
 #pragma unroll 2
         for (int kq = 0; kq < 36; ++kq) {

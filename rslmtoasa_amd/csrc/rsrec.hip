@@ -943,7 +943,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             } else if (u_hoh) {
                 double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
-                const dim3 g1 = level_grid(h, grid_mf, 2 * ll + 1), gl = level_grid(h, grid_mf, lv_final);
+                const dim3 gl = level_grid(h, grid_mf, lv_final);
                 k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), kp_only ? psi : ukp, hkp);
                 SD.level = lv_final;
                 k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, kp_only ? psi : ukp);
