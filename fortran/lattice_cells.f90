@@ -93,6 +93,7 @@ contains
             nc(l) = max(1, int((smax(l) - smin(l))/w(l)))
          end if
       end do
+      nc = min(nc, 1024)                              ! (wider cells stay correct; keeps the products below within integer(8))
       ! no more cells than atoms are worth having (merging cells keeps them wide enough)
       do while (int(nc(1), 8)*nc(2)*nc(3) > 8_8*nat)
          l = maxloc(nc, 1)
