@@ -50,6 +50,11 @@ CASES = {
     "fccCu001_block_hoh": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 2, "recur": "'block'", "lld": 12}, "hamiltonian": {"hoh": ".true."}}),
     "fccCu001_cheb": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 2, "recur": "'chebyshev'", "lld": 12}, "hamiltonian": {"hoh": ".false."}, "energy": {"energy_min": -3.0, "energy_max": 1.8}}),
 }
+# Green-function-only variants: same recursion inputs as the base case (tests pair them with <base>.npz), other terminator options
+GREEN_ONLY = {
+    # control%sym_term = .true.: orbital-independent terminator (green.f90:1263-1275)
+    "bccFe_nsp2_block_symterm": ("tests/scf/cases/bulk/bccFe", {"control": {"nsp": 2, "recur": "'block'", "lld": 20, "sym_term": ".true."}, "hamiltonian": {"hoh": ".false."}}),
+}
 
 
 def patch_namelist(text, patch):
@@ -113,7 +118,7 @@ def run_green_case(name):
     """<name>_green.npz: inputs and the reference's output of green%block_green for the same run as <name>.npz:
     a_b (reference coefficients), sqrt(B^2) after zsqr, the terminator (get_terminf), the energy mesh and g0 on a
     sub-sampled set of energies (every energy is an independent continued fraction, green.f90:1257-1336)."""
-    case_dir, patch = CASES[name]
+    case_dir, patch = CASES[name] if name in CASES else GREEN_ONLY[name]
     scratch = tempfile.mkdtemp(prefix="rsrec_gx_%s_" % name)
     try:
         for fn in os.listdir(os.path.join(REF, case_dir)):
@@ -214,7 +219,7 @@ SUPERCELLS = {
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES])
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)])
     for n in want:
         if n.endswith("_green"):
             run_green_case(n[:-len("_green")])

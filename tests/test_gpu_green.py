@@ -13,7 +13,12 @@ from rslmtoasa_amd.recursion import Recursion
 
 pytestmark = pytest.mark.gpu
 
-GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
+GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh",
+               "bccFe_nsp2_block_symterm"]      # (sym_term = T: orbital-independent terminator; recursion inputs of bccFe_nsp2_block)
+
+
+def base_case(name):
+    return name.replace("_symterm", "")
 
 
 def load_green(name):
@@ -30,7 +35,7 @@ def per_energy_err(g, ref):
 def test_block_green_from_reference_coefficients(name, oracle_lib):
     """Isolates the Green kernel: reference coefficients in, reference g0 out."""
     z = load_green(name)
-    g = load_golden(name)
+    g = load_golden(base_case(name))
     rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
     n = int(z["nrec"])
     rec.a_b[:, :, :, :n] = z["a_b"]
@@ -50,7 +55,7 @@ def test_recursion_zsqr_green_pipeline(name):
     """GPU recursion -> GPU zsqr -> GPU Green function, against the reference's g0 (terminator from the reference run:
     get_terminf stays on the CPU in the reference too).  LDOS = -Im g_jj / pi must be non-negative."""
     z = load_green(name)
-    g = load_golden(name)
+    g = load_golden(base_case(name))
     rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
     rec.recur_b()
     rec.zsqr()
