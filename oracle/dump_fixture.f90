@@ -42,7 +42,10 @@ program dump_fixture
    type(dos), target :: dos_obj
    type(green), target :: green_obj
    real(rp), allocatable :: a_inf(:, :, :), b_inf(:, :, :), a_inf0(:), b_inf0(:)
-   integer :: nw, nen, sym_i
+   integer :: nw, nen, sym_i, ieta, fpt
+   integer, parameter :: neta = 5
+   complex(rp) :: eta_c
+   complex(rp), allocatable :: g_ef(:, :, :)
    integer :: ia, u, kind_rec, nslots, hoh_i, nsites, ncheb
    real(rp) :: acheb, bcheb
    character(len=32) :: pre
@@ -172,6 +175,18 @@ program dump_fixture
       write (u) b_inf
       write (u) recursion_obj%b2_b
       write (u) green_obj%g0(:, :, 1:nen, 1:lattice_obj%nrec)
+      ! ---- green%block_green_eta (green.f90:544-579): bgreen at single energy points with a complex energy increment eta
+      !      (the Gauss-Legendre contour of the exchange code); NETA (point, eta) pairs, g_ef(18,18,site) each
+      write (u) int(z'47524e33'), neta, 0
+      allocate (g_ef(18, 18, atoms_per_process))
+      do ieta = 1, neta
+         fpt = 1 + ((nen - 1)*(ieta - 1))/(neta - 1)
+         eta_c = cmplx(0.002_rp*mod(ieta, 3), 0.004_rp*ieta, rp)
+         g_ef = (0.0_rp, 0.0_rp)
+         call green_obj%block_green_eta(eta_c, fpt, g_ef)
+         write (u) fpt, eta_c
+         write (u) g_ef(:, :, 1:lattice_obj%nrec)
+      end do
    case (1)
       write (u) recursion_obj%mu_n
       ! ---- the stage right after the Chebyshev recursion (self.f90:824): green%chebyshev_green (green.f90:1030-1108)

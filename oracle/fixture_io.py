@@ -16,6 +16,7 @@ import numpy as np
 
 MAGIC = 0x52534658
 GREEN_MAGIC = 0x47524e31
+ETA_GREEN_MAGIC = 0x47524e33
 CHEB_GREEN_MAGIC = 0x47524e32
 KIND_BLOCK, KIND_CHEB, KIND_SCALAR, KIND_BLOCK_IJ, KIND_CHEB_IJ = 0, 1, 2, 3, 4
 
@@ -64,6 +65,17 @@ def read_fixture_bin(path):
             d["green"] = dict(nen=nen, sym_term=sym, ene=_rd(f, np.float64, (nen,)), a_inf=_rd(f, np.float64, (18, 18, nrec)),
                               b_inf=_rd(f, np.float64, (18, 18, nrec)), b_sqrt=_rd(f, np.complex128, (18, 18, lld, nrec)),
                               g0=_rd(f, np.complex128, (18, 18, nen, nrec)))
+            tail = f.read(12)
+            if tail:
+                # green%block_green_eta (green.f90:544-579): (energy point, eta) pairs and g at that point
+                emagic, neta, _ = struct.unpack("<iii", tail)
+                assert emagic == ETA_GREEN_MAGIC
+                pts, etas, gs = [], [], []
+                for _ in range(neta):
+                    pts.append(struct.unpack("<i", f.read(4))[0])
+                    etas.append(complex(*struct.unpack("<dd", f.read(16))))
+                    gs.append(_rd(f, np.complex128, (18, 18, nrec)))
+                d["green"].update(eta_points=np.array(pts, np.int32), eta=np.array(etas, np.complex128), g_eta=np.stack(gs, axis=2))   # (18,18,neta,nrec)
             assert f.read(1) == b"", "trailing bytes in fixture"
     return d
 

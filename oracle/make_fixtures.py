@@ -147,6 +147,8 @@ def run_green_case(name):
                    ene_full_first=g["ene"][0], ene_full_step=g["ene"][1] - g["ene"][0],
                    a_inf=g["a_inf"], b_inf=g["b_inf"], a_b=d["a_b"], b_sqrt=g["b_sqrt"], g0=g["g0"][:, :, idx, :],
                    source_case=np.array(case_dir), namelist_patch=np.array(repr(patch)))
+        if "eta" in g:      # block_green_eta: 1-based energy points, complex increments, g(18,18,neta,nrec)
+            out.update(eta_points=g["eta_points"], eta=g["eta"], g_eta=g["g_eta"], ene_eta=g["ene"][g["eta_points"] - 1])
         path = os.path.join(GOLD, name + "_green.npz")
         np.savez_compressed(path, **out)
         print("%-24s green: nen=%d kept=%d nrec=%d lld=%d sym_term=%d -> %.1f KB" % (name, g["nen"], len(idx), d["nrec"], d["lld"], g["sym_term"],

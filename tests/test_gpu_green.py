@@ -50,6 +50,25 @@ def test_block_green_from_reference_coefficients(name, oracle_lib):
     rec.close()
 
 
+@pytest.mark.parametrize("name", ["bccFe_nsp2_block", "bccFe_nsp2_block_symterm", "B2FeCo_block_hoh"])
+def test_block_green_eta_against_reference(name):
+    """bgreen with a complex energy increment (block_green_eta, green.f90:544-579): reference coefficients in, the reference's
+    g at five (energy point, eta) pairs out."""
+    z = load_green(name)
+    g = load_golden(base_case(name))
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
+    n = int(z["nrec"])
+    rec.a_b[:, :, :, :n] = z["a_b"]
+    rec.b2_b[:, :, :, :n] = z["b_sqrt"]
+    for k in range(len(z["eta"])):
+        gr = Green(rec, z["ene_eta"][k:k + 1], sym_term=bool(z["sym_term"]))
+        g0 = gr.block_green(z["a_inf"], z["b_inf"], eta=complex(z["eta"][k]), nsites=n)
+        for s in range(n):
+            ref = z["g_eta"][:, :, k, s]
+            assert np.abs(g0[:, :, 0, s] - ref).max() / np.abs(ref).max() < RTOL
+    rec.close()
+
+
 @pytest.mark.parametrize("name", GREEN_CASES)
 def test_recursion_zsqr_green_pipeline(name):
     """GPU recursion -> GPU zsqr -> GPU Green function, against the reference's g0 (terminator from the reference run:
