@@ -55,8 +55,58 @@ def main():
     exp = {k: float(re.search(r"(?im)^\s*%s\s*=\s*([-+0-9.eEdD]+)" % k, txt).group(1).replace("D", "E").replace("d", "e")) for k in ("etot", "ws_r", "vmad")}
     manifest["Regression_bccFe_lanczos"] = {"inputs": os.path.relpath(dst, OUT), "patch": {}, "expected": {"nml": {"Fe_out.nml": exp}},
                                             "abs_tol": 1e-6, "rel_tol": 0.0, "source": "tests/regression/bccFe_lanczos/Fe.nml.ref (abs 1e-6, tests/regression/test_comparison.py:77)"}
+    manifest.update(generated_cases())
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
     print("wrote", len(manifest), "cases to", OUT)
+
+
+def generated_cases():
+    """Cases the reference's own test suite does not hold: expected values produced HERE by running the compiled reference
+    (oracle/_ref/rslmto_ref.x, oracle/build_ref.sh) on a variant of one of its cases.
+    Generated_bulk_bccFe_nsp4_local_axis: hamiltonian%local_axis = T with the moment tilted to (0.6, 0, 0.8): recur_b re-rotates
+    every Hamiltonian block into the site's spin frame before its chain (recursion.f90:1830-1832)."""
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from oracle.make_fixtures import patch_namelist
+    exe = os.path.join(ROOT, "oracle", "_ref", "rslmto_ref.x")
+    out = {}
+    name = "Generated_bulk_bccFe_nsp4_local_axis"
+    dst = os.path.join(OUT, "inputs", "bulk_bccFe_tilted")
+    os.makedirs(dst, exist_ok=True)
+    src = os.path.join(REF, "tests/scf/cases/bulk/bccFe")
+    shutil.copy(os.path.join(src, "input.nml"), os.path.join(dst, "input.nml"))
+    fe = open(os.path.join(src, "Fe.nml")).read()
+    fe = re.sub(r"(?m)^(\s*mom\s*=\s*).*$", r"\g<1>0.6000000000000000, 0.0000000000000000, 0.8000000000000000", fe, count=1)
+    open(os.path.join(dst, "Fe.nml"), "w").write(fe)
+    for fn in ("input.nml", "Fe.nml"):
+        os.chmod(os.path.join(dst, fn), 0o644)
+    patch = {"control": {"nsp": "4", "recur": "'block'", "lld": "20"}, "self": {"nstep": "1"}, "hamiltonian": {"hoh": ".false.", "local_axis": ".true."}}
+    work = tempfile.mkdtemp(prefix="rsrec_scf_gen_")
+    try:
+        for fn in ("input.nml", "Fe.nml"):
+            shutil.copy(os.path.join(dst, fn), os.path.join(work, fn))
+        p = os.path.join(work, "input.nml")
+        txt_in = patch_namelist(open(p).read(), patch)
+        open(p, "w").write(txt_in)
+        env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
+        r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=work, env=env, capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        txt = open(os.path.join(work, "Fe_out.nml")).read()
+
+        def val(key, idx=0):
+            m = re.search(r"(?im)^\s*%s\s*=\s*(.+)$" % key, txt)
+            return [float(v.replace("D", "E").replace("d", "e")) for v in re.findall(r"[-+]?[0-9]*\.?[0-9]+(?:[eEdD][-+]?[0-9]+)?", m.group(1))][idx]
+        rows = open(os.path.join(work, "totaldos.out")).read().splitlines()
+        text = {str(rw): {"1": float(rows[rw - 1].split()[0]), "2": float(rows[rw - 1].split()[1])} for rw in (500, 1000, 1500)}
+        out[name] = {"inputs": os.path.relpath(dst, OUT), "patch": patch,
+                     "expected": {"nml": {"Fe_out.nml": {"etot": val("etot"), "ws_r": val("ws_r"), "mom": {"3": val("mom", 2)}}}, "text": {"totaldos.out": text}},
+                     "abs_tol": 1e-6, "rel_tol": 1e-6,
+                     "source": "generated: oracle/_ref/rslmto_ref.x (the compiled reference) run by oracle/make_scf_fixtures.py on tests/scf/cases/bulk/bccFe with mom = (0.6, 0, 0.8), local_axis = T"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":
