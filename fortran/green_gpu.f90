@@ -5,7 +5,7 @@
 ! MODULE: green_gpu_mod
 !
 ! DESCRIPTION:
-!> `type, extends(green) :: green_gpu` overrides ONE procedure of the reference's `green` type: `bgreen`
+!> `type, extends(green) :: green_gpu` overrides the continued fraction of the reference's `green` type, `bgreen` (and its all-sites driver `block_green`, to batch the sites)
 !> (green.f90:1191-1339), the continued fraction  coefficients -> g(E)  that `block_green` (:588), `block_green_eta`
 !> (:541) and the inter-site variants call per site.  Everything else -- the terminator (`recursion%get_terminf`, CPU),
 !> the result arrays `g0, gij, ...`, `sgreen`, `chebyshev_green` -- is inherited.  The GPU side is `rsrec_block_green`
@@ -31,6 +31,7 @@ module green_gpu_mod
    type, public, extends(green) :: green_gpu
    contains
       procedure :: bgreen => gpu_bgreen
+      procedure :: block_green => gpu_block_green
       procedure :: chebyshev_green => gpu_chebyshev_green
    end type green_gpu
 
@@ -90,6 +91,46 @@ contains
       if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
       g_out(:, :, ie_start:ie_start + ie_len - 1) = gt
    end subroutine gpu_bgreen
+
+   !> Replaces green.f90:588-621: the per-site loop over `bgreen` becomes ONE library call for all sites of this rank, so the
+   !> kernel of one chunk of sites overlaps the download of the previous one (rsrec.hip green_pipeline) instead of a
+   !> launch + 13 MB copy per site.  Terminator exactly as the reference computes it (get_terminf stays on the CPU).
+   subroutine gpu_block_green(this)
+      use mpi_mod, only: start_atom, end_atom, g2l_map, atoms_per_process
+      class(green_gpu), intent(inout) :: this
+      integer :: nw, ll, ldim, nv, nloc, n1
+      integer(c_int) :: rc, sym_i
+      type(c_ptr) :: handle
+      real(rp), dimension(this%lattice%nrec) :: a_inf0, b_inf0
+      real(rp), dimension(18, 18, this%lattice%nrec) :: a_inf, b_inf
+      real(rp), allocatable, target :: ene(:), ai(:, :, :), bi(:, :, :)
+      complex(rp), allocatable, target :: ab(:, :, :, :), bs(:, :, :, :), gt(:, :, :, :)
+
+      ll = this%control%lld
+      ldim = 18
+      nw = 10*ll
+      call this%recursion%get_terminf(this%recursion%a_b, this%recursion%b2_b, atoms_per_process, &
+                                      ll, ldim, nw, a_inf, b_inf, a_inf0, b_inf0)
+      nloc = end_atom - start_atom + 1
+      if (nloc <= 0) return
+      n1 = g2l_map(start_atom)                               ! local indices of the rank's sites are contiguous (mpi.f90:72-78)
+      nv = this%en%channels_ldos + 10
+      allocate (ene(nv), ai(18, 18, nloc), bi(18, 18, nloc), ab(18, 18, ll, nloc), bs(18, 18, ll, nloc), gt(18, 18, nv, nloc))
+      ene = this%en%ene(1:nv)
+      ai = a_inf(:, :, n1:n1 + nloc - 1)
+      bi = b_inf(:, :, n1:n1 + nloc - 1)
+      ab = this%recursion%a_b(:, :, 1:ll, n1:n1 + nloc - 1)
+      bs = this%recursion%b2_b(:, :, 1:ll, n1:n1 + nloc - 1)  ! sqrt(B^2): zsqr ran before (self.f90:829)
+      sym_i = 0
+      if (this%control%sym_term) sym_i = 1
+      handle = rsrec_gpu_context()
+      call g_timer%start('bgreen-gpu')
+      rc = rsrec_block_green(handle, int(nloc, c_int), int(ll, c_int), int(nv, c_int), c_loc(ene), 0.0_c_double, 0.0_c_double, sym_i, &
+                             c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), c_loc(gt))
+      call g_timer%stop('bgreen-gpu')
+      if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
+      this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
+   end subroutine gpu_block_green
 
    !> Replaces green.f90:1030-1108: g0 of the sites of this rank from the Chebyshev moments.  The side effect of the reference
    !> routine -- recursion%mu_ng = mu_n * Jackson kernel (* 2 beyond the first moment), read later by bands.f90:762 -- is kept.
