@@ -86,7 +86,7 @@ contains
       handle = rsrec_gpu_context()
       call g_timer%start('bgreen-gpu')
       rc = rsrec_block_green(handle, 1_c_int, int(ll, c_int), int(ie_len, c_int), c_loc(ene), real(eta, c_double), aimag(eta), sym_i, &
-                             c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), c_loc(gt))
+                             c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), gt)
       call g_timer%stop('bgreen-gpu')
       if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
       g_out(:, :, ie_start:ie_start + ie_len - 1) = gt
@@ -115,7 +115,7 @@ contains
       if (nloc <= 0) return
       n1 = g2l_map(start_atom)                               ! local indices of the rank's sites are contiguous (mpi.f90:72-78)
       nv = this%en%channels_ldos + 10
-      allocate (ene(nv), ai(18, 18, nloc), bi(18, 18, nloc), ab(18, 18, ll, nloc), bs(18, 18, ll, nloc), gt(18, 18, nv, nloc))
+      allocate (ene(nv), ai(18, 18, nloc), bi(18, 18, nloc), ab(18, 18, ll, nloc), bs(18, 18, ll, nloc))
       ene = this%en%ene(1:nv)
       ai = a_inf(:, :, n1:n1 + nloc - 1)
       bi = b_inf(:, :, n1:n1 + nloc - 1)
@@ -125,11 +125,18 @@ contains
       if (this%control%sym_term) sym_i = 1
       handle = rsrec_gpu_context()
       call g_timer%start('bgreen-gpu')
-      rc = rsrec_block_green(handle, int(nloc, c_int), int(ll, c_int), int(nv, c_int), c_loc(ene), 0.0_c_double, 0.0_c_double, sym_i, &
-                             c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), c_loc(gt))
+      if (n1 == 1 .and. size(this%g0, 3) == nv .and. size(this%g0, 4) >= nloc) then
+         ! green%g0(18,18,nv,atoms_per_process) (green.f90:192) is the library's output buffer itself: no staging copy of 13 MB per site
+         rc = rsrec_block_green(handle, int(nloc, c_int), int(ll, c_int), int(nv, c_int), c_loc(ene), 0.0_c_double, 0.0_c_double, sym_i, &
+                                c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), this%g0)
+      else
+         allocate (gt(18, 18, nv, nloc))
+         rc = rsrec_block_green(handle, int(nloc, c_int), int(ll, c_int), int(nv, c_int), c_loc(ene), 0.0_c_double, 0.0_c_double, sym_i, &
+                                c_loc(ai), c_loc(bi), c_loc(ab), c_loc(bs), gt)
+         if (rc == 0) this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
+      end if
       call g_timer%stop('bgreen-gpu')
       if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
-      this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
    end subroutine gpu_block_green
 
    !> Replaces green.f90:1030-1108: g0 of the sites of this rank from the Chebyshev moments.  The side effect of the reference
@@ -161,16 +168,22 @@ contains
          this%recursion%mu_ng(:, :, 2:nm, n) = this%recursion%mu_ng(:, :, 2:nm, n)*2.0_rp
       end do
       n1 = g2l_map(start_atom)
-      allocate (ene(nv), mu(18, 18, nm, nloc), gt(18, 18, nv, nloc))
+      allocate (ene(nv), mu(18, 18, nm, nloc))
       ene = this%en%ene(1:nv)
       mu = this%recursion%mu_n(:, :, 1:nm, n1:n1 + nloc - 1)
       handle = rsrec_gpu_context()
       call g_timer%start('chebyshev-green-gpu')
-      rc = rsrec_chebyshev_green(handle, int(nloc, c_int), int(this%control%lld, c_int), int(nv, c_int), c_loc(ene), &
-                                 real(this%en%energy_min, c_double), real(this%en%energy_max, c_double), c_loc(mu), c_loc(gt))
+      if (n1 == 1 .and. size(this%g0, 3) == nv .and. size(this%g0, 4) >= nloc) then
+         rc = rsrec_chebyshev_green(handle, int(nloc, c_int), int(this%control%lld, c_int), int(nv, c_int), c_loc(ene), &
+                                    real(this%en%energy_min, c_double), real(this%en%energy_max, c_double), c_loc(mu), this%g0)
+      else
+         allocate (gt(18, 18, nv, nloc))
+         rc = rsrec_chebyshev_green(handle, int(nloc, c_int), int(this%control%lld, c_int), int(nv, c_int), c_loc(ene), &
+                                    real(this%en%energy_min, c_double), real(this%en%energy_max, c_double), c_loc(mu), gt)
+         if (rc == 0) this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
+      end if
       call g_timer%stop('chebyshev-green-gpu')
       if (rc /= 0) call g_logger%fatal('rsrec_chebyshev_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
-      this%g0(:, :, 1:nv, n1:n1 + nloc - 1) = gt
    end subroutine gpu_chebyshev_green
 
 end module green_gpu_mod

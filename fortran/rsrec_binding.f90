@@ -45,21 +45,23 @@ module rsrec_binding
 
       function rsrec_block_green(handle, nsites, lld, nen, ene, eta_re, eta_im, sym_term, a_inf, b_inf, a_b, b_sqrt, g0) &
          bind(C, name='rsrec_block_green') result(rc)
-         import :: c_int, c_ptr, c_double
+         import :: c_int, c_ptr, c_double, c_double_complex
          type(c_ptr), value :: handle
          integer(c_int), value :: nsites, lld, nen, sym_term
          real(c_double), value :: eta_re, eta_im
-         type(c_ptr), value :: ene, a_inf, b_inf, a_b, b_sqrt, g0
+         type(c_ptr), value :: ene, a_inf, b_inf, a_b, b_sqrt
+         complex(c_double_complex), dimension(*), intent(inout) :: g0   ! by address: green%g0 itself can be the target (833 MB for 64 sites: no staging copy)
          integer(c_int) :: rc
       end function
 
       function rsrec_chebyshev_green(handle, nsites, lld, nen, ene, energy_min, energy_max, mu_n, g0) &
          bind(C, name='rsrec_chebyshev_green') result(rc)
-         import :: c_int, c_ptr, c_double
+         import :: c_int, c_ptr, c_double, c_double_complex
          type(c_ptr), value :: handle
          integer(c_int), value :: nsites, lld, nen
          real(c_double), value :: energy_min, energy_max
-         type(c_ptr), value :: ene, mu_n, g0
+         type(c_ptr), value :: ene, mu_n
+         complex(c_double_complex), dimension(*), intent(inout) :: g0   ! by address (see rsrec_block_green)
          integer(c_int) :: rc
       end function
 
