@@ -60,6 +60,9 @@ struct rsrec_handle {
     std::string err;
     // lattice (host copies for the region search + device tables)
     bool have_lattice = false, have_ham = false;
+    std::vector<int32_t> lat_nn, lat_iz;   // the caller's tables as last uploaded: an SCF loop passes the same lattice every iteration
+    int lat_nncols = 0;
+    std::vector<double> lat_cr;
     int kk = 0, nslots = 0, nmax = 0, ntype = 0;
     std::vector<int> nbr;        // [kk][nslots] 0-based, -1 absent, slot 0 = self
     std::vector<int> iz0;        // 0-based types
@@ -361,6 +364,12 @@ extern "C" void rsrec_site_partition(int rank, int nprocs, int nsites, int* star
 extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* nn, const int32_t* iz, int nmax, int ntype) {
     if (!h || !nn || !iz || kk <= 0 || nncols < 1 || nmax < 0 || nmax > kk || ntype < 1) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: bad argument");
     HIPCK(h, hipSetDevice(h->device));
+    // unchanged lattice (every SCF iteration of the reference calls the drivers with the same lattice%nn): keep the device tables
+    // and, above all, the cached regions -- building them costs as much host time as the recursion costs device time
+    if (h->have_lattice && kk == h->kk && nncols == h->lat_nncols && nmax == h->nmax && ntype == h->ntype &&
+        h->lat_nn.size() == (size_t)kk * nncols && std::memcmp(h->lat_nn.data(), nn, h->lat_nn.size() * sizeof(int32_t)) == 0 &&
+        std::memcmp(h->lat_iz.data(), iz, (size_t)kk * sizeof(int32_t)) == 0)
+        return RSREC_OK;
     int nslots = 1;
     for (int i = 0; i < kk; ++i) {
         const int nr = nn[i];
@@ -408,6 +417,10 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
         HIPCK(h, hipMemcpy(h->d_nbr5.p, n5.data(), n5.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     spatial_key_from_graph(h);
+    h->lat_nn.assign(nn, nn + (size_t)kk * nncols);
+    h->lat_iz.assign(iz, iz + kk);
+    h->lat_nncols = nncols;
+    h->lat_cr.clear();
     h->have_lattice = true;
     h->lattice_epoch++;
     h->have_ham = false;   // operator tables depend on nmax/ntype: must be set again
@@ -418,6 +431,8 @@ extern "C" int rsrec_set_positions(rsrec_t* h, const double* cr) {
     if (!h || !cr) return fail(h, RSREC_ERR_ARG, "rsrec_set_positions: bad argument");
     if (!h->have_lattice) return fail(h, RSREC_ERR_ARG, "rsrec_set_positions: call rsrec_set_lattice first");
     const int kk = h->kk;
+    if (h->lat_cr.size() == 3 * (size_t)kk && std::memcmp(h->lat_cr.data(), cr, h->lat_cr.size() * sizeof(double)) == 0) return RSREC_OK;
+    h->lat_cr.assign(cr, cr + 3 * (size_t)kk);
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int i = 0; i < kk; ++i)
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], cr[3 * (size_t)i + a]); hi[a] = std::max(hi[a], cr[3 * (size_t)i + a]); }

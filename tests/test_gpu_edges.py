@@ -46,3 +46,29 @@ def test_more_chains_than_one_batch_and_zero_sites(oracle_lib):
     rec0 = Recursion(*objects_from(p, np.zeros(0, np.int32), 6), device=0)
     rec0.recur_b()                                            # no sites on this rank: a no-op, like the reference's empty loop
     rec0.close()
+
+
+def test_unchanged_lattice_keeps_the_cached_regions():
+    """Every SCF iteration of the reference hands over the same lattice%nn (the Fortran shim calls rsrec_set_lattice before every
+    driver call): an identical table must not throw away the cached regions; a changed one must take effect."""
+    from helpers import objects_from, supercell_problem
+    from rslmtoasa_amd.recursion import Recursion
+    p = supercell_problem((11, 11, 11))
+    sites = np.array([1, 500, 900, 1331], dtype=np.int32)
+    rec = Recursion(*objects_from(p, sites, 10))
+    rec.recur_b()
+    t_first = rec.timing()["host_ms"]
+    a0 = rec.a_b.copy()
+    rec.update_lattice()                   # same tables again
+    rec.update_hamiltonian()
+    rec.recur_b()
+    assert np.array_equal(a0, rec.a_b)
+    assert rec.timing()["host_ms"] < max(0.2 * t_first, 0.5), (t_first, rec.timing()["host_ms"])    # no breadth-first search this time
+    nn = rec.lattice.nn.copy()
+    nn[0, 2] = 0                           # atom 1 loses one neighbour: a different operator
+    rec.lattice.nn = nn
+    rec.update_lattice()
+    rec.update_hamiltonian()
+    rec.recur_b()
+    assert np.abs(rec.a_b[:, :, :, 0] - a0[:, :, :, 0]).max() > 1e-6      # (first visible in A_3: psi_2 vanishes on the seed atom)
+    rec.close()
