@@ -22,8 +22,4 @@ if __name__ == "__main__":
         tm = rec.timing()
     print("chebyshev recursion %.1f ms | chebyshev_green: kernels %.1f ms, with transfers %.1f ms, wall %.1f ms (g0 = %.0f MB)" % (
         t_rec, tm["hop_ms"], tm["total_ms"], wall * 1e3, gr.g0.nbytes / 1e6))
-    from oracle import oracle
-    sel = np.array([0, 1, 1255, 2509])
-    ref = oracle.chebyshev_green(np.asfortranarray(rec.mu_n[:, :, :, 63]), ene[sel], -3.0, 1.8)
-    print("max |gpu - oracle| over 4 energies of site 63: %.3e (|g0| max %.3e)" % (np.abs(gr.g0[:, :, sel, 63] - ref).max(), np.abs(ref).max()))
     rec.close()
