@@ -1216,7 +1216,14 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve(std::max((size_t)B * nblk * 2 * BLK * sizeof(double2), (size_t)B * 256 * 2 * 1296 * sizeof(double))));
     h->p2_slot = (size_t)B * 16 * 2 * 1296;
-    HIPCK(h, h->d_partial2.reserve(h->p2_slot * sizeof(double)));
+    HIPCK(h, h->d_partial2.reserve(2 * h->p2_slot * sizeof(double)));
+    if (!h->side_stream) {
+        HIPCK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIPCK(h, hipEventCreateWithFlags(&h->ev_orth, hipEventDisableTiming));
+        HIPCK(h, hipEventCreateWithFlags(&h->ev_bred, hipEventDisableTiming));
+    }
+    const bool side = h->opt_side && h->side_stream;     // moment reduction of level t under the SpMM of level t + 1 (it feeds nothing on the device)
+    bool red_pending = false;
     HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
@@ -1295,6 +1302,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += hoh ? 2 : 1;
                 double* gp = h->d_partial.as<double>();
+                if (red_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); red_pending = false; }   // gp is free again
                 if (first) {
                     if (use_kp) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
                     else k_mfma_cheb<true, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
@@ -1302,8 +1310,15 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                     if (use_kp) k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
                     else k_mfma_cheb<false, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 }
-                int n2 = gl.x; const double* gp2 = presum(h, gp, nb, n2, 2 * 1296);
-                k_reduce_cheb_mf<<<nb, 1024, 0, h->stream>>>(gp2, n2, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                hipStream_t rs = h->stream;
+                if (side) {
+                    HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
+                    HIPCK(h, hipStreamWaitEvent(h->side_stream, h->ev_orth, 0));
+                    rs = h->side_stream;
+                }
+                int n2 = gl.x; const double* gp2 = presum(h, gp, nb, n2, 2 * 1296, rs, side ? 1 : 0);
+                k_reduce_cheb_mf<<<nb, 1024, 0, rs>>>(gp2, n2, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); red_pending = true; }
                 if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
                 continue;
             }
@@ -1340,6 +1355,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }   // psi0 <- psi1 <- psi2 (:2585-2587) by rotating buffers
         }
         HIPCK(h, hipGetLastError());
+        if (red_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); red_pending = false; }
         XFER(xfer_d2h(h, mu_n + (size_t)c0 * mstride * 2, mu, (size_t)nb * mstride * sizeof(double2)));
         HIPCK(h, hipStreamSynchronize(h->stream));
     }

@@ -205,13 +205,19 @@ def test_side_stream_is_invisible(hoh):
     coefficients are bit-identical with the option off, on a launch wide enough for the two-stage partial sums (11^3 cell)."""
     p = supercell_problem((11, 11, 11), hoh=hoh)
     sites = np.array([1, 700, 1331], dtype=np.int32)
-    rec = Recursion(*objects_from(p, sites, 12))
+    rec = Recursion(*objects_from(p, sites, 12, emin=-3.0, emax=1.8))
     rec.recur_b()
     a1, b1 = rec.a_b.copy(), rec.b2_b.copy()
     rec.set_option("side_stream", 0)
     rec.recur_b()
     assert np.array_equal(a1, rec.a_b) and np.array_equal(b1, rec.b2_b)
     assert np.isfinite(a1).all() and np.abs(b1[:, :, 1:, :]).max() > 0.0
+    # the same for the Chebyshev moments (their reduction runs under the next level's SpMM)
+    rec.chebyshev_recur()
+    m0 = rec.mu_n.copy()
+    rec.set_option("side_stream", 1)
+    rec.chebyshev_recur()
+    assert np.array_equal(m0, rec.mu_n) and np.abs(m0).max() > 0.0
     rec.close()
 
 
