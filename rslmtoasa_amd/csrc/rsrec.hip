@@ -13,12 +13,14 @@
 //  * reductions are two-stage and fixed-order (no float atomics) so results are run-to-run reproducible.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rsrec.h"
@@ -582,8 +584,10 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     }
     if (grouped) while (sat_list.size() % GROUP) sat_list.push_back(-1);
     const int sat_count = (int)sat_list.size();
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int c = 0; c < nb; ++c) {
+    // One region per chain, built by a few short-lived host threads.  (Not OpenMP: its idle workers spin for 200 ms after a
+    // parallel region -- one per visible CPU, 256 on the GPU boxes -- and burn the process's CPU quota: the host thread was then
+    // descheduled for 60-90 ms at a time during the next two or three calls, inside whatever HIP call it happened to be in.)
+    auto build_chain = [&](int c) {
         Region R;
         grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, R);
         int* orow = order.data() + (size_t)c * ostride;
@@ -637,6 +641,18 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             b_m += uses[lev_of[n]] * fan;
         }
         as[c] = a_s; bm[c] = b_m;
+    };
+    {
+        const int nthr = std::max(1, std::min({nb, 8, (int)std::thread::hardware_concurrency()}));
+        if (nthr == 1) {
+            for (int c = 0; c < nb; ++c) build_chain(c);
+        } else {
+            std::atomic<int> next_chain{0};
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; ++t)
+                pool.emplace_back([&]() { for (int c = next_chain++; c < nb; c = next_chain++) build_chain(c); });
+            for (auto& th : pool) th.join();
+        }
     }
     double as_sum = 0.0, bm_sum = 0.0;
     for (int c = 0; c < nb; ++c) { as_sum += as[c]; bm_sum += bm[c]; }

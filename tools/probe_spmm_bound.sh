@@ -10,7 +10,7 @@ mkdir -p $ROOT/build/probe
 cd $ROOT/rslmtoasa_amd/csrc
 for P in 1 2 3; do
   if [ ! -f $ROOT/build/probe/librsrec_p$P.so ] || [ rsrec.hip -nt $ROOT/build/probe/librsrec_p$P.so ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -Wno-unused-function -DS5_PROBE=$P -DS4_PROBE=$P -shared rsrec.hip -o $ROOT/build/probe/librsrec_p$P.so
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -Wno-unused-function -DS5_PROBE=$P -DS4_PROBE=$P -shared rsrec.hip -o $ROOT/build/probe/librsrec_p$P.so
   fi
 done
 if python3 -c "import ctypes; ctypes.CDLL('$ROOT/rslmtoasa_amd/librsrec.so').rsrec_device_count() > 0 or exit(1)" 2>/dev/null; then
