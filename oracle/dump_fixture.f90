@@ -43,6 +43,7 @@ program dump_fixture
    type(green), target :: green_obj
    real(rp), allocatable :: a_inf(:, :, :), b_inf(:, :, :), a_inf0(:), b_inf0(:)
    integer :: nw, nen, sym_i, ieta, fpt
+   integer(8) :: tc0, tc1, tc2, trate
    integer, parameter :: neta = 5
    complex(rp) :: eta_c
    complex(rp), allocatable :: g_ef(:, :, :)
@@ -165,8 +166,14 @@ program dump_fixture
       nen = energy_obj%channels_ldos + 10
       allocate (a_inf(18, 18, lattice_obj%nrec), b_inf(18, 18, lattice_obj%nrec), a_inf0(lattice_obj%nrec), b_inf0(lattice_obj%nrec))
       nw = 10*control_obj%lld
+      call system_clock(tc0, trate)
       call recursion_obj%get_terminf(recursion_obj%a_b, recursion_obj%b2_b, atoms_per_process, control_obj%lld, 18, nw, a_inf, b_inf, a_inf0, b_inf0)
+      call system_clock(tc1)
       call green_obj%block_green()
+      call system_clock(tc2)
+      write (*, '(a, f9.4, a, f9.4, a, i4, a)') ' dump_fixture: get_terminf ', real(tc1 - tc0)/real(trate), ' s, block_green (incl. its own get_terminf) ', &
+         real(tc2 - tc1)/real(trate), ' s for ', lattice_obj%nrec, ' site(s)'
+
       sym_i = 0
       if (control_obj%sym_term) sym_i = 1
       write (u) int(z'47524e31'), nen, sym_i
