@@ -23,6 +23,11 @@ import sys
 import tempfile
 import time
 
+# the host side of a rank is one thread driving one GPU: keep the BLAS / OpenMP pools of numpy and torch small (one rank per GPU,
+# up to 8 ranks per node; idle pools of one thread per visible CPU only add scheduler load)
+for _k in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_k, "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
