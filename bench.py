@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the recursion hot path (BASELINE.json).
 
-Workload (configs[1] of BASELINE.json): bcc Fe periodic supercell 22^3 = 10 648 atoms, spin-polarised 18x18
+Default workload (configs[1] of BASELINE.json): bcc Fe periodic supercell 22^3 = 10 648 atoms, spin-polarised 18x18
 complex blocks (physical Fe stencil dumped from the reference's tests/scf/cases/bulk/bccFe), block-Lanczos
 recursion with LL = 50.  One "step" = one full `recur_b` pass (recursion.f90:1807) over a batch of S = 64
 recursion sites per GPU: 49 recursion levels of H|psi>, A_n, B_n^2, 18x18 eigen-solve and vector update for
 every site.  Lattice tables and Hamiltonian blocks are resident in HBM before the timed region; the timed
 region contains everything `recur_b` does per call (region search, kernels, coefficients back to the host)
-and, for N > 1, the one packed RCCL all-reduce that gathers the per-site diagonal coefficients exactly like
-the reference's MPI_ALLREDUCE-as-allgather (bands.f90:271-274).
+and, for N > 1, the one RCCL all-reduce that gathers the per-site diagonal coefficients exactly like the
+reference's MPI_ALLREDUCE-as-allgather (bands.f90:271-274) -- packed and reduced on the device.
+
+Other workloads of BASELINE.json (same metric, named in config.workload):
+  --cells 46              configs[2]: 46^3 = 97 336 atoms (the 10^5-atom north-star cell), 64 sites per GPU
+  --hoh                   H = h - h o h + e_nu + l.s (hop_b_hoh, recursion.f90:1411)
+  --recur chebyshev       configs[3] shape: Chebyshev moments (chebyshev_recur, recursion.f90:3057)
+  --spin-mixing           the same stencil in a spin frame tilted by 60 degrees: every hopping block has spin-flip entries
+                          (non-collinear operator; nothing is skipped as a structural zero)
 
 Sites are independent: with N GPUs every rank owns S sites (weak scaling), no collective inside the loop.
 
-usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
+usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 without WORLD_SIZE in the environment: this process only launches `python -m torch.distributed.run --nproc-per-node N`
+  on itself (it never touches the GPU) and relays the ranks' output; under torch.distributed.run WORLD_SIZE must equal N.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -23,82 +32,17 @@ import sys
 import tempfile
 import time
 
-# the host side of a rank is one thread driving one GPU: keep the BLAS / OpenMP pools of numpy and torch small (one rank per GPU,
-# up to 8 ranks per node; idle pools of one thread per visible CPU only add scheduler load)
-for _k in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
-    os.environ.setdefault(_k, "8")
-
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-from rslmtoasa_amd.lattice import bcc_supercell, spread_sites, supercell_positions  # noqa: E402
-from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (public spec); rate measured here: profiles/ubench_f64_r01.txt
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_BLOCK_MULT = 46656.0   # 18x18x18 complex MACs x 8 flop
-# Memory-side bytes per H|psi> launch of the DEFAULT workload (22^3 atoms, 64 sites, LL=50), from separate rocprofv3 --pmc passes
-# (profiles/r01_final_rocprof_summary.txt): 2 x FETCH_SIZE (gfx950 reads 1/2, MI355X_MICROARCH.md) + WRITE_SIZE = 29.2 GB + 3.0 GB.
-# The counters sit on the L2's fabric side, so Infinity-Cache hits of the neighbour gathers are included.
-HOP_TRAFFIC_BYTES_PER_LAUNCH = 32.2e9
 CPU_SAMPLE_SITES = 10
-BYTES_PER_ATOM_STEP = 51840.0   # 10 blocks of 5184 B per active atom per level, H_B = 0 (stencil operator)
+BYTES_PER_ATOM_STEP = {"block": 51840.0, "chebyshev": 15552.0}   # 10 resp. 3 blocks of 5184 B per active atom per level, H_B = 0
+POST_FLOP_BLOCKS = {"block": 5.0, "chebyshev": 2.0}              # (nb + 5) resp. (nb + 2) x 46 656 flop per atom-step
 
 
-def load_stencil():
-    with np.load(os.path.join(ROOT, "tests", "golden", "bccFe_nsp2_block.npz"), allow_pickle=False) as z:
-        return z["ee"], z["lsham"], z["slot_vec"]
-
-
-def cpu_baseline(nn, ee, lsham, lld, threads):
-    """CPU leg on the host cores of this node, bounded sample = ONE site of the same workload (same lattice, LL).
-
-    Preferred: the compiled reference itself (oracle/_ref/ref_kernel.x, built in the build container from the
-    reference sources; it is the reference's own recur_b/crecal_b/hop_b with MKL + OpenMP).  Fallback: the C
-    restatement in oracle/ ("port")."""
-    flop = None
-    from rslmtoasa_amd.lattice import active_region_sizes
-    sizes = [1] + active_region_sizes(nn, 1, lld - 1)
-    # exact algorithmic work of one chain (matches SURVEY.md 8d: 384.7 GFLOP for this config)
-    nb = int(nn[0, 0])
-    mults = sum(nb * s for s in sizes[:-1])
-    atom_steps = sum(sizes[1:])
-    flop = FLOP_PER_BLOCK_MULT * (mults + 5 * atom_steps)
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_kernel.x")
-    if os.path.exists(exe):
-        try:
-            sys.path.insert(0, ROOT)
-            from oracle import fixture_io as fio
-            scratch = tempfile.mkdtemp(prefix="rsrec_cpu_")
-            kk = nn.shape[0]
-            nsample = CPU_SAMPLE_SITES          # bounded sample: ~10-30 s of CPU work on 16 cores
-            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=spread_sites(kk, nsample), lld=lld, nsp=2, hoh=0, kind=0, ee=ee, lsham=lsham)
-            fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
-            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G")
-            r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=scratch, env=env, capture_output=True, text=True, timeout=600)
-            t = None
-            for line in r.stdout.splitlines():
-                if "recursion wall time" in line:
-                    t = float(line.split()[-2])
-            if r.returncode == 0 and t:
-                return {"value": nsample * flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "kind": "reference", "seconds": t,
-                        "sites_per_s": nsample / t,
-                        "sample": "%d sites of the same %d-atom cell, LL=%d (%.1f GFLOP), compiled reference recur_b via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (nsample, kk, lld, nsample * flop * 1e-9)}
-        except Exception as e:  # noqa
-            print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
-    from oracle import oracle
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    o = oracle.Oracle(dict(nn=nn, iz=np.ones(nn.shape[0], np.int32), ee=ee, lsham=lsham, hoh=0, nsp=2))
-    t0 = time.time()
-    o.block_lanczos(np.array([1], np.int32), lld)
-    t = time.time() - t0
-    return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "kind": "port", "seconds": t,
-            "sample": "1 site of the same 10648-atom cell, LL=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (lld, flop * 1e-9)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -106,44 +50,238 @@ def main():
     ap.add_argument("--sites", type=int, default=64, help="recursion sites per GPU per step")
     ap.add_argument("--cells", type=int, default=22, help="n for the n^3 periodic bcc supercell")
     ap.add_argument("--lld", type=int, default=50)
+    ap.add_argument("--recur", choices=("block", "chebyshev"), default="block")
+    ap.add_argument("--hoh", action="store_true")
+    ap.add_argument("--spin-mixing", action="store_true", help="stencil rotated into a tilted spin frame: spin-flip entries in every block")
     ap.add_argument("--kernels", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--spmm4", type=int, default=-1, help="SpMM kernel: 0 = 16x16x4 MFMA, 1 = 4x4x4 MFMA one wave per group, 4 = 4x4x4 cooperative; -1 = library default")
+    ap.add_argument("--spmm4", type=int, default=-1, help="small-launch SpMM kernel selection (library option); -1 = library default")
     ap.add_argument("--no-positions", action="store_true", help="do not pass atom positions (locality hint)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development sweeps), may be repeated")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-green", action="store_true", help="skip the (untimed, separately reported) Green-function stage")
+    ap.add_argument("--no-green", action="store_true", help="skip the (untimed, separately reported) LDOS stage")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_ranks(args):
+    """--gpus N > 1 outside torch.distributed.run: start N ranks as a child job.  This parent never imports torch or loads
+    librsrec (a process that has touched the GPU must not spawn/exec the job, and needs no device itself)."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def load_stencil(hoh):
+    import numpy as np
+    name = "bccFe_nsp2_block_hoh.npz" if hoh else "bccFe_nsp2_block.npz"
+    with np.load(os.path.join(ROOT, "tests", "golden", "bccFe_nsp2_block.npz"), allow_pickle=False) as z:
+        slot_vec = z["slot_vec"]
+    with np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False) as z:
+        d = {k: z[k] for k in ("ee", "lsham") + (("eeo", "enim") if hoh else ())}
+    d["slot_vec"] = slot_vec
+    return d
+
+
+def tilt_spin_frame(st, theta):
+    """H' = U^H H U with U = exp(-i theta sigma_y / 2) (x) 1_9 applied to every block: the same physical operator written in a
+    spin frame tilted by theta about y.  Hopping blocks of a collinear magnet, diagonal in spin in the global frame
+    (hamiltonian.f90:1553-1617), acquire up/down entries -- what a non-collinear (nsp = 3/4, rotated moments) run feeds hop_b."""
+    import numpy as np
+    c, s = np.cos(theta / 2), np.sin(theta / 2)
+    U = np.kron(np.array([[c, -s], [s, c]]), np.eye(9)).astype(np.complex128)
+    out = dict(st)
+    for k in ("ee", "eeo"):
+        if k in st:
+            out[k] = np.einsum("ab,bcst,cd->adst", U.conj().T, st[k], U)
+    for k in ("lsham", "enim"):
+        if k in st:
+            out[k] = np.einsum("ab,bct,cd->adt", U.conj().T, st[k], U)
+    return out
+
+
+def scrubbed_env(extra):
+    """Environment for the CPU-baseline child: nothing of a profiler's preload may reach it (the child must not initialise the GPU)."""
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX", "ROCTRACER"))}
+    env.update(extra)
+    return env
+
+
+def cpu_quota():
+    """CPU bandwidth limit of this container (cgroup v2 cpu.max / v1 cfs quota), in CPUs; None if unlimited/unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
+    """CPU leg on the host cores of this node, bounded sample = a few sites of the same workload (same lattice, LL).
+
+    Preferred: the compiled reference itself (oracle/_ref/ref_kernel.x, built in the build container from the
+    reference sources: the reference's own recur_b / chebyshev_recur with MKL + OpenMP; SURVEY 8c planned the C port
+    for this leg, the compiled reference is the stronger baseline and the task statement allows it as kind "reference").
+    Fallback: the C restatement in oracle/ ("port")."""
+    import numpy as np
+    import resource
+    from rslmtoasa_amd.lattice import active_region_sizes, spread_sites
+    napply = lld - 1 if recur == "block" else lld + 1
+    sizes = [1] + active_region_sizes(nn, 1, (2 if hoh else 1) * napply)
+    nb = int(nn[0, 0])
+    if not hoh:
+        mults = sum(nb * s for s in sizes[:napply])
+        atom_steps = sum(sizes[1:napply + 1])
+    else:   # two applications per level (+2 on-site products), post-hop work on the region after both
+        mults = sum(nb * (sizes[2 * t] + sizes[2 * t + 1]) + 2 * sizes[2 * t] for t in range(napply))
+        atom_steps = sum(sizes[2 * t + 2] for t in range(napply))
+    flop = FLOP_PER_BLOCK_MULT * (mults + POST_FLOP_BLOCKS[recur] * atom_steps)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_kernel.x")
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) or k == "HSA_TOOLS_LIB" for k in os.environ)
+    if profiled:
+        print("cpu_baseline skipped: running under a profiler (its preload must not reach a child process)", file=sys.stderr)
+        return None
+    kk = nn.shape[0]
+    what = "recur_b" if recur == "block" else "chebyshev_recur"
+    if os.path.exists(exe):
+        try:
+            from oracle import fixture_io as fio
+            scratch = tempfile.mkdtemp(prefix="rsrec_cpu_")
+            nsample = max(1, min(CPU_SAMPLE_SITES, int(round(4.0e12 / flop))))          # bounded sample: ~4 TFLOP = 10-30 s of CPU work on 16 cores
+            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=spread_sites(kk, nsample), lld=lld, nsp=2, hoh=int(hoh), kind=0 if recur == "block" else 1,
+                     ee=st["ee"], lsham=st["lsham"], emin=emin, emax=emax)
+            if hoh:
+                p.update(eeo=st["eeo"], enim=st["enim"])
+            fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
+            env = scrubbed_env(dict(OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G"))
+
+            def unlimited_stack():      # the reference's automatic arrays overflow the default stack (SURVEY 8c)
+                resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+            r = subprocess.run([exe], cwd=scratch, env=env, capture_output=True, text=True, timeout=900, preexec_fn=unlimited_stack)
+            t = None
+            for line in r.stdout.splitlines():
+                if "recursion wall time" in line:
+                    t = float(line.split()[-2])
+            if r.returncode == 0 and t:
+                return {"value": nsample * flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
+                        "kind": "reference", "seconds": t, "sites_per_s": nsample / t,
+                        "sample": "%d sites of the same %d-atom cell, LL=%d (%.1f GFLOP), compiled reference %s via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (nsample, kk, lld, nsample * flop * 1e-9, what)}
+            print("cpu_baseline(reference) failed rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]), file=sys.stderr)
+        except Exception as e:  # noqa
+            print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
+    from oracle import oracle
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    o = oracle.Oracle(dict(nn=nn, iz=np.ones(kk, np.int32), ee=st["ee"], lsham=st["lsham"], hoh=int(hoh), nsp=2,
+                           **({"eeo": st["eeo"], "enim": st["enim"]} if hoh else {})))
+    t0 = time.time()
+    if recur == "block":
+        o.block_lanczos(np.array([1], np.int32), lld)
+    else:
+        from rslmtoasa_amd.recursion import chebyshev_scaling
+        o.chebyshev(np.array([1], np.int32), lld, *chebyshev_scaling(emin, emax))
+    t = time.time() - t0
+    return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
+            "kind": "port", "seconds": t, "sites_per_s": 1.0 / t,
+            "sample": "1 site of the same %d-atom cell, LL=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (kk, lld, flop * 1e-9)}
+
+
+def ldos_stage(rec, gz, ene, nloc, step_s):
+    """zsqr + terminator + Green function + LDOS reduction for the sites of one step (second call = steady state of an SCF loop)."""
+    import numpy as np
+    from rslmtoasa_amd.green import Green
+    a_inf = np.repeat(gz["a_inf"][:, :, :1], nloc, axis=2)
+    b_inf = np.repeat(gz["b_inf"][:, :, :1], nloc, axis=2)
+    gr = Green(rec, ene)
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rec.zsqr()
+        gr.block_green(a_inf, b_inf, nsites=nloc)
+        tg = time.perf_counter() - t0
+    tmg = rec.timing()
+    return {"wall_ms": tg * 1e3, "kernel_ms": tmg["hop_ms"], "energies": len(ene), "sites_per_s_recursion_plus_ldos": nloc / (step_s + tg),
+            "note": "zsqr + rsrec_block_green (green.f90:1191 bgreen) for the sites of one step incl. the g0 download; terminator from the fixture; not in `value`"}
+
+
+def profiled_traffic(workload_key, kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summaries (profiles/traffic.json, written by
+    tools/profile_bench.sh + tools/summarize_pmc.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled as the guide's gfx950
+    correction prescribes).  Returns (bytes, source) or (None, None) when no profile of this workload is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tab = json.load(f)
+        e = tab.get(workload_key, {}).get(kernel)
+        if e:
+            return float(e["bytes_per_launch"]), e.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        launch_ranks(args)                      # never returns
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print("bench.py: WORLD_SIZE=%d but --gpus %d: refusing to report a wrong n_gpus" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # the host side of a rank is one thread driving one GPU: keep the BLAS / OpenMP pools of numpy and torch small
+    for k in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(k, "8")
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from rslmtoasa_amd.lattice import bcc_supercell, spread_sites, supercell_positions
+    from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion, site_partition
     import torch
     dist = None
-    # one process per GPU.  BENCH_REHEARSAL=1 (development only): several ranks share the GPUs that exist and talk over gloo,
-    # to exercise the N > 1 code path on a one-GPU box (RCCL refuses two ranks on one device)
+    # one process per GPU.  BENCH_REHEARSAL=1 (development / the 1-GPU test box only): the ranks share the GPUs that exist and
+    # talk over gloo (RCCL refuses two ranks on one device); the collective then runs on a host copy of the device image
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-    device_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
-    coll_device = "cpu" if rehearsal else "cuda"
+    ndev = torch.cuda.device_count()
+    if not rehearsal and world > ndev:
+        print("bench.py: --gpus %d but only %d device(s) visible" % (world, ndev), file=sys.stderr)
+        sys.exit(2)
+    device_index = local_rank % max(ndev, 1) if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(device_index)
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))   # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
+        backend = dist.get_backend()
 
-    ee, lsham, slot_vec = load_stencil()
+    st = load_stencil(args.hoh)
+    if args.spin_mixing:
+        st = tilt_spin_frame(st, np.pi / 3)
     n = args.cells
-    nn = bcc_supercell((n, n, n), slot_vec)
+    nn = bcc_supercell((n, n, n), st["slot_vec"])
     kk = nn.shape[0]
     nsites_total = args.sites * world
     irec = spread_sites(kk, nsites_total)
+    emin, emax = -3.0, 1.8          # Chebyshev window of the reference's Chebyshev cases (tests/golden/*_cheb.npz; SURVEY 8, C4)
     lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1, cr=None if args.no_positions else supercell_positions((n, n, n)))
-    ham = Hamiltonian(ee=ee, lsham=lsham, hoh=False)
-    ctl = Control(lld=args.lld, nsp=2, recur="block")
-    rec = Recursion(ham, lat, ctl, Energy(), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
+    ham = Hamiltonian(ee=st["ee"], lsham=st["lsham"], eeo=st.get("eeo"), enim=st.get("enim"), hoh=args.hoh)
+    ctl = Control(lld=args.lld, nsp=2, recur="block" if args.recur == "block" else "chebyshev")
+    rec = Recursion(ham, lat, ctl, Energy(energy_min=emin, energy_max=emax), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
     if args.kernels:
         rec.set_option("kernels", args.kernels)
     if args.batch:
@@ -154,16 +292,32 @@ def main():
         k, v = kv.split("=")
         rec.set_option(k, int(v))
 
-    from rslmtoasa_amd.parallel import allgather_sites
+    start, end = site_partition(rank, world, nsites_total)
+    img = None
+    if world > 1:
+        # device image of the per-site results of ALL ranks (zero-padded; all-reduce(sum) == all-gather, bands.f90:271-274)
+        img = torch.zeros((2, nsites_total, 18, args.lld) if args.recur == "block" else (nsites_total, 2 * args.lld + 2, 18, 18, 2),
+                          dtype=torch.float64, device="cuda")
 
     def step():
-        rec.recur_b()
+        if args.recur == "block":
+            rec.recur_b()
+        else:
+            rec.chebyshev_recur()
         if world > 1:
-            # the path's one exchange: zero-padded all-reduce == all-gather of the per-site results (bands.f90:271-274),
-            # here the diagonal coefficients a(ll,l,site), b2(ll,l,site) that feed the LDOS continued fraction
-            start, end = rec._my_sites()[:2]
-            nloc = end - start + 1
-            allgather_sites([rec.a[:args.lld, :, :nloc, 0], rec.b2[:args.lld, :, :nloc, 0]], rank, world, nsites_total, dist=dist, device=coll_device)
+            # the path's one exchange, on the device: the library writes this rank's part of the image straight into the tensor
+            # the collective reduces (no host round trip); gloo rehearsal reduces a host copy
+            if args.recur == "block":
+                rec.pack_diag(start - 1, nsites_total, img[0].data_ptr(), img[1].data_ptr())
+            else:
+                img.zero_()
+                img[start - 1:end].copy_(torch.from_numpy(np.ascontiguousarray(rec.mu_n[:, :, :, :end - start + 1].T).view(np.float64).reshape(end - start + 1, 2 * args.lld + 2, 18, 18, 2)))
+            if rehearsal:
+                hostimg = img.cpu()
+                dist.all_reduce(hostimg, op=dist.ReduceOp.SUM)
+                img.copy_(hostimg)
+            else:
+                dist.all_reduce(img, op=dist.ReduceOp.SUM)
 
     for _ in range(args.warmup):
         step()
@@ -184,27 +338,39 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if args.recur == "block":     # the gathered image holds every rank's sites: check this rank's and a remote rank's entries
+            a_img = img[0].cpu().numpy()
+            mine = rec.a[:args.lld, :, :end - start + 1, 0].transpose(2, 1, 0)
+            assert np.array_equal(a_img[start - 1:end], mine), "gathered image does not reproduce this rank's coefficients"
+            other = (start - 1 + args.sites) % nsites_total
+            assert np.abs(a_img[other]).max() > 0, "gathered image has no data from the other ranks"
 
     if rank == 0:
-        default_workload = (args.cells == 22 and args.sites == 64 and args.lld == 50 and not args.kernels and not args.batch
-                            and args.spmm4 < 0 and not args.no_positions and not args.opt)
+        variant = ("hoh " if args.hoh else "") + ("spin-mixing " if args.spin_mixing else "")
+        wl_key = "%s%s%s_c%d_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", "_mix" if args.spin_mixing else "", n, args.sites, args.lld)
+        tuned = bool(args.kernels or args.batch or args.spmm4 >= 0 or args.no_positions or args.opt)
         # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
-        flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + 5.0 * tm_acc["atom_steps"])
+        flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + POST_FLOP_BLOCKS[args.recur] * tm_acc["atom_steps"])
         flop_total = flop_rank * world
-        bytes_total = BYTES_PER_ATOM_STEP * tm_acc["atom_steps"] * world
+        bytes_total = BYTES_PER_ATOM_STEP[args.recur] * tm_acc["atom_steps"] * world
         # dominant kernel = H|psi>: the block SpMM, 46656 flop per block multiply (+ 46656 per atom-step when the kernel
         # also forms the A_n partial: VALU kernels and the fused MFMA variant)
-        hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + (tm_acc["atom_steps"] if tm.get("hop_fuses_a", 1.0) else 0.0))
+        fuses = tm.get("hop_fuses_a", 1.0) and args.recur == "block"
+        hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + (tm_acc["atom_steps"] if fuses else 0.0))
         hop_s = tm_acc["hop_ms"] * 1e-3
         achieved = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
+        step_tflops = flop_total / world / elapsed * 1e-12          # per-GPU whole-level rate
+        kernel = "k_spmm5"
+        traffic, traffic_src = (None, None) if tuned else profiled_traffic(wl_key, kernel)
         out = {
-            "metric": "block-recursion throughput (H|psi> + A_n + B_n recursion levels, recursion.f90 recur_b)",
+            "metric": ("block-recursion throughput (H|psi> + A_n + B_n recursion levels, recursion.f90 recur_b)" if args.recur == "block" else
+                       "Chebyshev-recursion throughput (H|psi> + moment levels, recursion.f90 chebyshev_recur)"),
             "value": flop_total / elapsed * 1e-9,
             "unit": "GFLOP/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -213,45 +379,43 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic periodic bcc lattice; physical Fe spd stencil (18x18 complex blocks) dumped from the reference's bulk/bccFe case",
-            "config": {"workload": "bcc Fe %d^3 = %d atoms, nsp=2 18x18 blocks, block Lanczos LL=%d, %d sites per GPU per step" % (n, kk, args.lld, args.sites),
-                       "sites_per_gpu": args.sites, "atoms": kk, "lld": args.lld, "parallelism": "site-partition x%d (get_mpi_variables rule), no collective in the loop" % world},
+            "config": {"workload": "bcc Fe %d^3 = %d atoms, nsp=2 18x18 blocks, %s%s LL=%d, %d sites per GPU per step"
+                                   % (n, kk, variant, "block Lanczos" if args.recur == "block" else "Chebyshev", args.lld, args.sites),
+                       "workload_key": wl_key, "sites_per_gpu": args.sites, "atoms": kk, "lld": args.lld,
+                       "parallelism": "site-partition x%d (get_mpi_variables rule), no collective in the loop" % world,
+                       "collective": None if world == 1 else "%s all-reduce of the zero-padded per-site image on the %s" % (backend, "host (rehearsal)" if rehearsal else "device")},
             "sites_per_s": nsites_total * args.steps / elapsed,
             "atom_steps_per_s": tm_acc["atom_steps"] * world / elapsed,
             "gbytes_per_s": bytes_total / elapsed * 1e-9,
             "device_ms_per_step": tm_acc["total_ms"] / args.steps,
             "host_ms_per_step": tm_acc["host_ms"] / args.steps,
+            # roofline of the dominant kernel (frac = frac_kernel) and of the whole recursion level (frac_step): the headline `value`
+            # divided by the same peak -- the whole-level number is the one to compare runs by
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": HOP_TRAFFIC_BYTES_PER_LAUNCH if default_workload else None, "kernel": ("k_spmm5" if default_workload else "k_spmm5 / k_spmm4") + " (H|psi> block SpMM, FP64 MFMA 4x4x4)" if not tm.get("hop_fuses_a", 1.0) else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
+                         "frac_kernel": achieved / FP64_PEAK_TFLOPS, "frac_step": step_tflops / FP64_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel + " (H|psi> block SpMM, FP64 MFMA)" if not fuses else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
-                         "hbm_view": {"achieved": bytes_total / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / elapsed * 1e-9 / HBM_PEAK_GBS,
-                                      "note": "whole recursion level, algorithmic 51840 B per atom-step"}},
+                         "flops_counted": "nominal 46656 per block multiply incl. structural zeros of spin-diagonal blocks" if not args.spin_mixing else "nominal 46656 per block multiply; spin-mixing blocks: nothing skipped",
+                         "hbm_view": {"achieved": bytes_total / world / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / world / elapsed * 1e-9 / HBM_PEAK_GBS,
+                                      "note": "whole recursion level per GPU, algorithmic %d B per atom-step" % BYTES_PER_ATOM_STEP[args.recur]}},
         }
-        if world == 1 and not args.no_green:
-            # Not part of `value`: the stage behind the recursion (zsqr + green%bgreen) for the same sites, once, so
-            # that "sites/s from Hamiltonian to g0" can be quoted.  Terminator (get_terminf, a CPU routine in the reference too)
-            # taken from the bulk bcc Fe fixture of the same Hamiltonian; 2510 energies = the reference's default mesh.
+        if world == 1 and not args.no_green and args.recur == "block":
+            # Not part of `value`: the LDOS stage behind the recursion for the same sites, entirely on the device from the resident
+            # coefficients (zsqr + get_terminf + bgreen + the -Im g0_jj/pi reduction of bands.f90:227-268), so that a true
+            # "sites/s from Hamiltonian to LDOS" can be quoted.  2510 energies = the reference's default mesh.
             try:
-                from rslmtoasa_amd.green import Green
                 gz = np.load(os.path.join(ROOT, "tests", "golden", "bccFe_nsp2_block_green.npz"), allow_pickle=False)
-                nloc = args.sites
                 ene = float(gz["ene_full_first"]) + float(gz["ene_full_step"]) * np.arange(int(gz["nen_full"]))
-                a_inf = np.repeat(gz["a_inf"][:, :, :1], nloc, axis=2); b_inf = np.repeat(gz["b_inf"][:, :, :1], nloc, axis=2)
-                gr = Green(rec, ene)
-                for _ in range(2):                                   # second call = steady state of an SCF loop (buffers exist)
-                    t0 = time.perf_counter()
-                    rec.zsqr()
-                    gr.block_green(a_inf, b_inf, nsites=nloc)
-                    tg = time.perf_counter() - t0
-                tmg = rec.timing()
-                out["green"] = {"wall_ms": tg * 1e3, "kernel_ms": tmg["hop_ms"], "energies": len(ene),
-                                "sites_per_s_recursion_plus_green": nloc / (elapsed / args.steps + tg),
-                                "note": "zsqr + rsrec_block_green (green.f90:1191 bgreen) for the sites of one step, incl. the g0 download; not in `value`"}
+                out["ldos"] = ldos_stage(rec, gz, ene, args.sites, elapsed / args.steps)
             except Exception as e:  # noqa
-                print("green stage skipped: %r" % (e,), file=sys.stderr)
+                print("LDOS stage skipped: %r" % (e,), file=sys.stderr)
         if world == 1 and not args.no_cpu:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(nn, ee, lsham, args.lld, threads)
-        print(json.dumps(out))
+            cb = cpu_baseline(nn, st, args.lld, threads, args.recur, args.hoh, emin, emax)
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
     rec.close()
     if world > 1:
         dist.destroy_process_group()

@@ -85,6 +85,16 @@ int rsrec_block_lanczos(rsrec_t *h, int nsites, const int32_t *seed_atoms, int l
 int rsrec_block_lanczos_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
                                int lld, double *a_b, double *b2_b);
 
+/* The per-site result the ranks exchange after the recursion, packed ON THE DEVICE from the coefficients the last
+ * rsrec_block_lanczos call left there: a(ll,l,site) = Re a_b(l,l,ll,site), b2 likewise (recursion.f90:1850-1851).
+ * The reference gathers per-site arrays with MPI_ALLREDUCE(MPI_IN_PLACE, ..., MPI_SUM) on zero-padded images
+ * (bands.f90:271-274); this writes such an image for this rank: sites site_offset+1 .. site_offset+nsites (the rank's
+ * start_atom-1 from rsrec_site_partition) are filled, every other site is zero, so one RCCL all-reduce(sum) over the
+ * ranks' images is the gather.
+ *   a_img, b2_img : real (lld, 18, nsites_total) out -- HOST or DEVICE memory (detected): a device buffer (e.g. the
+ *   tensor handed to the collective) is written in place, no host round trip. */
+int rsrec_pack_diag(rsrec_t *h, int site_offset, int nsites_total, double *a_img, double *b2_img);
+
 /* In-place principal square root of `nmat` Hermitian 18x18 matrices: b2_b <- sqrt(b2_b).
  * Replaces zsqr (recursion.f90:1980-2023). */
 int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);

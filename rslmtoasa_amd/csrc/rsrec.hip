@@ -107,6 +107,8 @@ struct rsrec_handle {
     const std::vector<int>* cur_level_max = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
+    // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root)
+    int res_kind = 0, res_n = 0, res_lld = 0, res_sqrt = 0;
 };
 
 namespace {
@@ -811,8 +813,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         HIPCK(h, hipEventCreateWithFlags(&h->ev_bred, hipEventDisableTiming));
     }
     HIPCK(h, h->d_frags.reserve((size_t)B * 4 * 27 * 64 * sizeof(double)));
-    HIPCK(h, h->d_coefA.reserve((size_t)B * lld * BLK * sizeof(double2)));
-    HIPCK(h, h->d_coefB.reserve((size_t)B * lld * BLK * sizeof(double2)));
+    // the coefficients of ALL chains of the call stay on the device (resident input of rsrec_pack_diag / rsrec_block_ldos)
+    h->res_kind = 0;
+    HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
+    HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_bmats.reserve((size_t)B * 2 * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
@@ -822,8 +826,6 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     double* pmn = h->d_vec[1].as<double>();
     double* hpsi = h->d_vec[2].as<double>();
     double* t2 = h->d_vec[3].as<double>();
-    double2* dA = h->d_coefA.as<double2>();
-    double2* dB = h->d_coefB.as<double2>();
     double2* partial = h->d_partial.as<double2>();
     double* gpartial = h->d_partial.as<double>();
     double* gpartial_b = gpartial + gram_elems;          // Gram partials of k_mfma_orth3 when their reduction runs on the side stream
@@ -840,6 +842,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
 
     for (int c0 = 0; c0 < nchains; c0 += B) {
         const int nb = std::min(B, nchains - c0);
+        double2* dA = h->d_coefA.as<double2>() + (size_t)c0 * cstride;       // this batch's slice of the resident coefficients
+        double2* dB = h->d_coefB.as<double2>() + (size_t)c0 * cstride;
         const auto th0 = std::chrono::steady_clock::now();
         std::vector<int> seeds0((size_t)nb * nseed);
         std::vector<double> coef((size_t)nb * nseed * 2);
@@ -1036,6 +1040,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     int status = 0;
     XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
+    h->res_kind = 1; h->res_n = nchains; h->res_lld = lld; h->res_sqrt = 0;
     return RSREC_OK;
 }
 
@@ -1059,6 +1064,51 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
 
 extern "C" int rsrec_block_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double* a_b, double* b2_b) {
     return rsrec_block_lanczos_seeded(h, nsites, 1, seed_atoms, nullptr, lld, a_b, b2_b);
+}
+
+namespace {
+
+// true if p is device memory of this process (torch / hipMalloc allocations): outputs may then stay on the GPU
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable host memory
+    return at.type == hipMemoryTypeDevice;
+}
+
+// a(ll, l, site) = Re a_b(l, l, ll, site), b2 likewise (recursion.f90:1850-1851), written into zero-padded images over all sites
+__global__ void k_pack_diag(const double2* __restrict__ A, const double2* __restrict__ B, int lld, int n, int off, int ntot,
+                            double* __restrict__ a_img, double* __restrict__ b_img) {
+    const size_t total = (size_t)lld * NB * ntot;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ll = (int)(e % lld), l = (int)((e / lld) % NB), s = (int)(e / ((size_t)lld * NB)) - off;
+        double a = 0.0, b = 0.0;
+        if (s >= 0 && s < n) {
+            const size_t q = ((size_t)s * lld + ll) * BLK + (size_t)l * (NB + 1);
+            a = A[q].x; b = B[q].x;
+        }
+        a_img[e] = a; b_img[e] = b;
+    }
+}
+
+}  // namespace
+
+// The per-site result the ranks exchange after the recursion, packed on the device: bands.f90:271-274 gathers per-site arrays with
+// MPI_ALLREDUCE(MPI_SUM) on zero-padded images; this writes this rank's part of such an image (every other site zero).
+extern "C" int rsrec_pack_diag(rsrec_t* h, int site_offset, int nsites_total, double* a_img, double* b2_img) {
+    if (!h || !a_img || !b2_img || site_offset < 0) return fail(h, RSREC_ERR_ARG, "rsrec_pack_diag: bad argument");
+    if (h->res_kind != 1) return fail(h, RSREC_ERR_ARG, "rsrec_pack_diag: no block-Lanczos coefficients resident (call rsrec_block_lanczos first)");
+    if (site_offset + h->res_n > nsites_total) return fail(h, RSREC_ERR_ARG, "rsrec_pack_diag: sites %d..%d outside 1..%d", site_offset + 1, site_offset + h->res_n, nsites_total);
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->res_lld * NB * nsites_total;
+    const bool dev = is_device_ptr(a_img) && is_device_ptr(b2_img);
+    double *da = a_img, *db = b2_img;
+    if (!dev) { HIPCK(h, h->d_scal.reserve(2 * n * sizeof(double))); da = h->d_scal.as<double>(); db = da + n; }
+    const int blocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+    k_pack_diag<<<blocks, 256, 0, h->stream>>>(h->d_coefA.as<double2>(), h->d_coefB.as<double2>(), h->res_lld, h->res_n, site_offset, nsites_total, da, db);
+    HIPCK(h, hipGetLastError());
+    if (!dev) { XFER(xfer_d2h(h, a_img, da, n * sizeof(double))); XFER(xfer_d2h(h, b2_img, db, n * sizeof(double))); }
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return RSREC_OK;
 }
 
 extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {

@@ -188,6 +188,14 @@ class Recursion:
         self.a[:lld, :, :n, 0] = a_b[d, d].real.transpose(1, 0, 2)    # :1850-1851
         self.b2[:lld, :, :n, 0] = b2_b[d, d].real.transpose(1, 0, 2)
 
+    def pack_diag(self, site_offset, nsites_total, a_img, b2_img):
+        """This rank's part of the zero-padded (lld, 18, nsites_total) images of a / b2 that the ranks all-reduce
+        (bands.f90:271-274), written from the coefficients resident on the device.  a_img / b2_img: numpy arrays or raw
+        (device) addresses, e.g. ``tensor.data_ptr()`` of the CUDA tensor handed to the collective."""
+        pa = a_img if isinstance(a_img, int) else a_img.ctypes.data
+        pb = b2_img if isinstance(b2_img, int) else b2_img.ctypes.data
+        self._check(self._L.rsrec_pack_diag(self._h, int(site_offset), int(nsites_total), C.c_void_p(pa), C.c_void_p(pb)))
+
     def recur_b_ij(self):
         """Four chains per atom pair, seeds (psi_i +- psi_j)/sqrt2 and (psi_i +- i psi_j)/sqrt2 (recursion.f90:1655-1800)."""
         lld = self.control.lld

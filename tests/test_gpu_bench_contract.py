@@ -32,12 +32,33 @@ def test_bench_single_gpu_small():
 
 
 def test_bench_two_ranks_rehearsal():
-    env = dict(os.environ, BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--sites", "8", "--cells", "10", "--lld", "12"]
+    """`bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (BENCH_REHEARSAL: they share the box's
+    one GPU and reduce over gloo; on a multi-GPU node the same command runs one rank per device over RCCL)."""
+    env = dict(os.environ, BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--sites", "8", "--cells", "10", "--lld", "12",
+           "--master-port", "29533"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = last_json(r.stdout)
     assert REQUIRED <= set(d)
     assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"] and d["value"] > 0
     assert "cpu_baseline" not in d                    # CPU leg on rank 0 at N = 1 only
+    assert "gloo" in d["config"]["collective"]
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_bench_step_fraction_is_value_over_peak():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--sites", "8", "--cells", "10", "--lld", "12",
+                        "--no-green", "--no-cpu", "--recur", "chebyshev"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    rf = d["roofline"]
+    assert abs(rf["frac_step"] - d["value"] * 1e-3 / d["n_gpus"] / rf["peak"]) < 1e-9 and rf["frac"] == rf["frac_kernel"]
+    assert "Chebyshev" in d["config"]["workload"]
