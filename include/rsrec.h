@@ -150,7 +150,6 @@ int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
  *   "three_term" block Lanczos formulation: 0 = the reference's literal order, 1 = normalised three-term, 2 = un-normalised (u-scheme) [2]
  *   "spmm4"      small-launch SpMM: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative [-1]
  *   "spmm5"      large-launch SpMM k_spmm5: 0 off, 1 auto (>= 4096 groups per launch; always for hoh), 2 always [1]
- *   "kp_only"    u vectors in the k-pair layout only (measured slower) [0]
  *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u> [1]
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
  *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none]

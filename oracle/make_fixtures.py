@@ -49,7 +49,13 @@ CASES = {
     # surface: 3 types, 2 recursion sites, fcc stencil (19 slots)
     "fccCu001_block_hoh": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 2, "recur": "'block'", "lld": 12}, "hamiltonian": {"hoh": ".true."}}),
     "fccCu001_cheb": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 2, "recur": "'chebyshev'", "lld": 12}, "hamiltonian": {"hoh": ".false."}, "energy": {"energy_min": -3.0, "energy_max": 1.8}}),
+    # SURVEY C4 at its full depth (lld = 50 -> 102 moments); outputs only, the inputs are those of fccCu001_cheb
+    "fccCu001_cheb50": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 2, "recur": "'chebyshev'", "lld": 50}, "hamiltonian": {"hoh": ".false."}, "energy": {"energy_min": -3.0, "energy_max": 1.8}}),
+    # scalar Haydock recursion beyond the one bulk case: three atom types (surface) and per-atom impurity blocks (nmax = 15)
+    "fccCu001_nsp1_lanczos": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 1, "recur": "'lanczos'", "lld": 12, "llsp": 12}, "hamiltonian": {"hoh": ".false."}}),
+    "B2FeCo_nsp1_lanczos": ("tests/scf/cases/impurity/B2FeCo", {"control": {"nsp": 1, "recur": "'lanczos'", "lld": 12, "llsp": 12}, "hamiltonian": {"hoh": ".false."}}),
 }
+OUTPUTS_ONLY = {"fccCu001_cheb50": "fccCu001_cheb"}      # name -> fixture that holds the (identical) inputs
 # Green-function-only variants: same recursion inputs as the base case (tests pair them with <base>.npz), other terminator options
 GREEN_ONLY = {
     # control%sym_term = .true.: orbital-independent terminator (green.f90:1263-1275)
@@ -102,6 +108,13 @@ def run_case(name):
         extra = {"source_case": np.array(case_dir), "namelist_patch": np.array(repr(patch))}
         if name == "bccFe_nsp2_block":
             extra["slot_vec"] = slot_vectors(d)
+        if name in OUTPUTS_ONLY:
+            base = fio.load_golden(os.path.join(GOLD, OUTPUTS_ONLY[name] + ".npz"))
+            for k in fio.INPUT_KEYS:
+                if k in base:
+                    assert np.array_equal(base[k], d[k]), "inputs of %s differ from %s: %s" % (name, OUTPUTS_ONLY[name], k)
+            d = {k: v for k, v in d.items() if k not in fio.INPUT_KEYS}
+            extra["inputs_from"] = np.array(OUTPUTS_ONLY[name])
         fio.save_golden(os.path.join(GOLD, name + ".npz"), d, extra)
         print("%-24s kk=%d nmax=%d nrec=%d lld=%d kind=%d hoh=%d -> %.1f KB" % (
             name, d["kk"], d["nmax"], d["nrec"], d["lld"], d["kind"], d["hoh"],
@@ -219,11 +232,33 @@ SUPERCELLS = {
 }
 
 
+def spread_case(name, threads=(1, 2, 8)):
+    """<name>_spread.npz: the compiled reference's OWN run-to-run spread on a supercell case -- the same ref_kernel.x run at
+    several OpenMP thread counts (its reductions are `omp reduction` sums, recursion.f90:1638-1645: the summation order depends
+    on the thread count).  Tests bound the GPU's deviation on ill-conditioned late levels by a multiple of this spread."""
+    cfg = SUPERCELLS[name]
+    outs = {}
+    for t in threads:
+        tmpname = "%s__t%d" % (name, t)
+        supercell_case(tmpname, threads=t, **cfg)
+        with np.load(os.path.join(GOLD, tmpname + ".npz"), allow_pickle=False) as z:
+            for k in fio.OUTPUT_KEYS:
+                if k in z.files:
+                    outs["%s_t%d" % (k, t)] = z[k]
+        os.remove(os.path.join(GOLD, tmpname + ".npz"))
+        os.remove(os.path.join(GOLD, tmpname + ".timer.txt"))
+    outs["threads"] = np.array(threads)
+    np.savez_compressed(os.path.join(GOLD, name + "_spread.npz"), **outs)
+    print("%-24s reference spread over threads %s" % (name + "_spread", threads))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)])
     for n in want:
-        if n.endswith("_green"):
+        if n.endswith("_spread"):
+            spread_case(n[:-len("_spread")])
+        elif n.endswith("_green"):
             run_green_case(n[:-len("_green")])
         elif n in CASES:
             run_case(n)

@@ -24,15 +24,18 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int GROUP = 8;            // atoms per wave (one type)
 constexpr int MF_WAVES = 4;         // waves per workgroup
 
-// element (orbital row r, re/im part, column c) of an 18x18 complex block in the KP layout (648 doubles, a bijection):
-// per spin sigma = r / 9 a 324-double half; real-form row w = 9 part + m (m = r % 9), k-pair p = w >> 3, lane row l4 = w & 3,
-// pair member e = (w >> 2) & 1; rows 16, 17 form the spin's fifth (half-empty) k-step.
-__host__ __device__ constexpr int kp_offset(int r, int part, int c) {
-    const int sigma = r / 9, m = r % 9, w = 9 * part + m, base = 324 * sigma;
-    if (c < 16) return w < 16 ? base + 128 * (w >> 3) + 32 * (w & 3) + 2 * c + ((w >> 2) & 1) : base + 256 + 16 * (w - 16) + c;
-    const int cc = c - 16;
-    return w < 16 ? base + 288 + 16 * (w >> 3) + 4 * (w & 3) + 2 * cc + ((w >> 2) & 1) : base + 320 + 2 * (w - 16) + cc;
-}
+// CI layout ("complex interleaved", the large-launch path's ONE vector layout): element (r, c) of an 18x18 block = one complex
+// number at doubles 36 r + 2 c (re), + 1 (im): row-major, the transpose of the reference's column-major block.  A row is 36
+// reals in memory order [re0 im0 re1 im1 ...]; the Gram / right-multiply kernels below work on such rows generically (they are
+// layout-blind: only the coefficient tables and the Gram -> complex conversion know whether real column j means
+// (part j / 18, c = j % 18) -- LayoutRM, the small-launch path -- or (part j & 1, c = j >> 1) -- CI).  k_spmm5 reads AND
+// writes CI with 16-byte accesses, so a vector exists once (round 1 kept a second "k-pair" copy for the SpMM).
+struct LayoutCI {
+    static __device__ __forceinline__ double2 ld(const double* b, int r, int c) { return make_double2(b[36 * r + 2 * c], b[36 * r + 2 * c + 1]); }
+    static __device__ __forceinline__ void st(double* b, int r, int c, double2 v) { b[36 * r + 2 * c] = v.x; b[36 * r + 2 * c + 1] = v.y; }
+};
+// real column of (part, c) inside a 36-real row
+__host__ __device__ constexpr int gram_col(int part, int c, int ci) { return ci ? 2 * c + part : 18 * part + c; }
 
 constexpr int FRAG_PER_SLOT = 9 * 3 * 64;   // doubles: [q][f][lane]
 
@@ -260,16 +263,9 @@ __device__ __forceinline__ void gram_block_out(const GramAcc& A, double* lds /*[
 }
 
 // ---- A_n partial: Gm = sum_rows psihat^T * that   (hop_b :1642) -------------------------------------------------------
-// PSI_KP: psi is stored in the k-pair layout (kp_offset)
-template <bool PSI_KP>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, int level, int zero_block, const double* __restrict__ psi,
                                                                const double* __restrict__ tvec, double* partial /*[chain][nblk][1296]*/) {
     __shared__ double lds[MF_WAVES * 1296];
-    __shared__ unsigned short kpt[PSI_KP ? BLD : 1];
-    if (PSI_KP) {
-        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
-        __syncthreads();
-    }
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -287,12 +283,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
 #pragma unroll 4
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);               // k-row of this lane
-            double p0, p1, pr;
-            if (PSI_KP) {
-                const unsigned blk = (rk.off / BLD) * BLD;
-                const unsigned short* t = kpt + (rk.off - blk);
-                p0 = ps[blk + t[l15]]; p1 = ps[blk + t[16 + l15]]; pr = ps[blk + t[32 + l3]];
-            } else { p0 = ps[rk.off + l15]; p1 = ps[rk.off + 16 + l15]; pr = ps[rk.off + 32 + l3]; }
+            const double p0 = ps[rk.off + l15], p1 = ps[rk.off + 16 + l15], pr = ps[rk.off + 32 + l3];
             const double h0 = tv[rk.off + l15], h1 = tv[rk.off + 16 + l15], hr = tv[rk.off + 32 + l3];
             A.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h0, A.t00, 0, 0, 0);
             A.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h1, A.t01, 0, 0, 0);
@@ -586,7 +577,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, WPS) void k_mfma_spmm(SpmmDims D, co
 
 // ---- reductions of the 36x36 real partials ----------------------------------------------------------------------------
 // returns C[cp + 18 c] (complex) for tid < 324:  C_re = G[re cp][re c] + G[im cp][im c],  C_im = G[re cp][im c] - G[im cp][re c]
-__device__ __forceinline__ double2 reduce_gram(const double* __restrict__ partial /*[nblk][1296]*/, int nblk, double* lds /*1296*/) {
+__device__ __forceinline__ double2 reduce_gram(const double* __restrict__ partial /*[nblk][1296]*/, int nblk, double* lds /*1296*/, int ci = 0) {
     for (int e = threadIdx.x; e < 1296; e += blockDim.x) {
         double s = 0.0;
         for (int p = 0; p < nblk; ++p) s += partial[(size_t)p * 1296 + e];
@@ -596,8 +587,9 @@ __device__ __forceinline__ double2 reduce_gram(const double* __restrict__ partia
     double2 c = make_double2(0, 0);
     if (threadIdx.x < BLK) {
         const int cp = threadIdx.x % NB, cc = threadIdx.x / NB;
-        c.x = lds[36 * cp + cc] + lds[36 * (18 + cp) + 18 + cc];
-        c.y = lds[36 * cp + 18 + cc] - lds[36 * (18 + cp) + cc];
+        const int rp = gram_col(0, cp, ci), ip = gram_col(1, cp, ci), rc = gram_col(0, cc, ci), ic = gram_col(1, cc, ci);
+        c.x = lds[36 * rp + rc] + lds[36 * ip + ic];
+        c.y = lds[36 * rp + ic] - lds[36 * ip + rc];
     }
     __syncthreads();
     return c;

@@ -11,9 +11,11 @@
 //     granularity and ONE WAVE OWNS ONE SPIN of a group of 8 atoms: 45 accumulators instead of 162, so two waves fit
 //     on a SIMD and cover each other's issue stalls.  Spin-mixing blocks (spin-orbit on-site term, non-collinear
 //     operators) take the same path with both input spins.
-//   * the input vector is read in the k-pair ("KP") layout written by the producing kernel (k_mfma_orth3, k_rm_to_kp):
-//     the B operands of two consecutive k-steps are adjacent, so one 16-byte load feeds two MFMA k-steps; the operator
-//     fragments are stored the same way.  Per slot and wave: 42 loads for 225 MFMAs (before: 130 for 441).
+//   * the work vectors are complex-interleaved row-major ("CI", kernels_mfma.hpp) and the real form's k order is chosen so that
+//     the real and imaginary part of one element are the B operands of two consecutive k-steps: one 16-byte load feeds two
+//     MFMA k-steps; the operator fragments are stored the same way.  Per slot and wave: 42 loads for 225 MFMAs (before: 130
+//     for 441).  (Round 1 used a separate "k-pair" copy of the vector for this; CI is the ONE layout of the large-launch path:
+//     the Gram / orthogonalisation kernels read and write it with the same 16-byte accesses.)
 //   * neighbour blocks are wave-uniform: their addresses are SGPR bases, the lane part of every address is one of three
 //     loop-invariant registers, everything else an instruction immediate: no address arithmetic on the vector ALU.
 #pragma once
@@ -55,11 +57,19 @@ struct Spmm5Operator {
         if (d_meta) (void)hipFree(d_meta);
         d_frag = nullptr; d_meta = nullptr; frag_bytes = meta_bytes = 0;
     }
-    // entry (row ko, column ki) of the padded 40x40 real form: index = 20 sigma + w, w = 9 part + m, w = 18, 19 are padding
+    // entry (row ko, column ki) of the padded 40x40 real form: index = 20 sigma + rho.  rho = 4 s + l (k-step s, lane row l):
+    // s = 2 P + e < 4 -> (part e, m = 4 P + l); s = 4 -> l = 0: (re, m = 8), l = 1: (im, m = 8), l = 2, 3: padding -- the two
+    // members of a k-pair are the real and imaginary part of ONE complex element of the vector (layout CI below)
+    static bool decode20(int rho, int& part, int& m) {
+        const int st = rho >> 2, l = rho & 3;
+        if (st < 4) { part = st & 1; m = 4 * (st >> 1) + l; return true; }
+        if (l < 2) { part = l; m = 8; return true; }
+        return false;
+    }
     static double real40(const double* blk, int ko, int ki) {
         const int so = ko / 20, wo = ko % 20, si = ki / 20, wi = ki % 20;
-        if (wo >= 18 || wi >= 18) return 0.0;
-        const int po = wo / 9, mo = wo % 9, pi = wi / 9, mi = wi % 9;
+        int po, mo, pi, mi;
+        if (!decode20(wo, po, mo) || !decode20(wi, pi, mi)) return 0.0;
         const int ro = 9 * so + mo, ri = 9 * si + mi;
         const double hr = blk[2 * (ro + 18 * ri)], hi = blk[2 * (ro + 18 * ri) + 1];
         if (po == pi) return hr;
@@ -153,8 +163,8 @@ __device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, unsigne
                                              unsigned lane_main, unsigned lane_rem, unsigned lane16) {
     if (!(LOOP && (S5_PROBE & 2))) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1024 * P);
-        o.b[8] = *reinterpret_cast<const s5_d2*>(S.base + spin_off + (S.rem + lane_rem) + 128 * P);
+        for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1152 * P);
+        o.b[8] = *reinterpret_cast<const s5_d2*>(S.base + spin_off + (S.rem + lane_rem) + 1152 * P);
     }
     if (!(LOOP && (S5_PROBE & 1))) {
 #pragma unroll
@@ -279,10 +289,9 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 }
 
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
-// different spin) land on the same SIMD.  in_kp: KP layout; out: LayoutRM (read by the Gram / orthogonalisation kernels).
-// OUT_KP: write the result in the KP layout instead (first pass of hoh: its result is only read by the second pass).
+// different spin) land on the same SIMD.  Input and output vectors in the CI layout.
 // TWO: second input vector for the extra on-site slot (second pass of hoh).
-template <bool OUT_KP, bool TWO>
+template <bool TWO>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
@@ -292,8 +301,10 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const unsigned lane_main = 8u * (32 * l4 + 2 * l15), lane_single = 8u * (256 + 16 * (l4 & 1) + l15);
-    const unsigned lane_rem = 8u * (288 + 4 * l4 + 2 * (l15 & 1)), lane_rem_single = 8u * (320 + 2 * (l4 & 1) + (l15 & 1));
+    // CI layout (kernels_mfma.hpp): element (r, c) of a block = complex at doubles 36 r + 2 c; row r = 9 sigma + m.  k-pair P of
+    // input spin sigma = rows m = 4 P + l4 (re, im = the pair's two k-steps); single k-step = row m = 8 (lane row 0: re, 1: im)
+    const unsigned lane_main = 8u * (36 * l4 + 2 * l15), lane_single = 8u * (288 + 2 * l15 + (l4 & 1));
+    const unsigned lane_rem = 8u * (36 * l4 + 32 + 2 * (l15 & 1)), lane_rem_single = 8u * (288 + 32 + 2 * (l15 & 1) + (l4 & 1));
     const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
     // A workgroup serves the chains blockIdx.y, blockIdx.y + gridDim.y, ...: a 512-thread, 256-register workgroup lives only
     // 25-50 us per chain, so its launch cost is amortised over several chains (grid.y < number of chains)
@@ -344,64 +355,22 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 
         s5_run_slots<TWO>(acc, M, fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
-        // D layout: row w = 4 rb + l4 of spin sig (w = 18, 19: padding, exact zeros, not stored), column l15
-        if (!OUT_KP) {
+        // D layout: real-form row rho = 4 rb + l4 of spin sig, column l15.  rb = 2 P + e is (part e, m = 4 P + l4): the accumulators
+        // (2P, 2P+1) are the real and imaginary part of element (m, c) -> one 16-byte store in the CI layout; rb = 4: m = 8
 #pragma unroll
-            for (int rb = 0; rb < 5; ++rb) {
-                const int w = 4 * rb + l4;
-                if (w >= 18) continue;
-                const int ro = 36 * (9 * sig + (w % 9)) + 18 * (w / 9);
+        for (int t = 0; t < 9; ++t) {
+            const int a = (t < 8) ? atom[t] : my_rem_atom;
+            if (a == zero_block) continue;
+            double* ob = out + (size_t)BLD * a + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1));
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int a = (t < 8) ? atom[t] : my_rem_atom;
-                    if (a == zero_block) continue;
-                    out[(size_t)BLD * a + ro + ((t < 8) ? l15 : 16 + (l15 & 1))] = acc[rb][t];
-                }
+            for (int p = 0; p < 2; ++p) {
+                s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
+                *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
             }
-        } else {
-            // KP layout: row blocks (2p, 2p+1) are the two members of k-pair p -> one 16-byte store; rb = 4 is the single k-step
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int a = (t < 8) ? atom[t] : my_rem_atom;
-                if (a == zero_block) continue;
-                double* ob = out + (size_t)BLD * a + 324 * sig;
-                if (t < 8) {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
-                        *reinterpret_cast<s5_d2*>(ob + 128 * p + 32 * l4 + 2 * l15) = v;
-                    }
-                    if (l4 < 2) ob[256 + 16 * l4 + l15] = acc[4][t];
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
-                        *reinterpret_cast<s5_d2*>(ob + 288 + 16 * p + 4 * l4 + 2 * (l15 & 1)) = v;
-                    }
-                    if (l4 < 2) ob[320 + 2 * l4 + (l15 & 1)] = acc[4][t];
-                }
-            }
+            if (l4 < 2) ob[288 + l4] = acc[4][t];
         }
     }
     }   // chains of this workgroup
-}
-
-// LayoutRM -> KP copy of the blocks of one region list (seed blocks; paths whose producer does not write KP itself)
-__global__ __launch_bounds__(256) void k_rm_to_kp(ChainView CV, int level, const double* __restrict__ src, double* __restrict__ dst) {
-    const int chain = blockIdx.y;
-    const int count = CV.count_of(chain, level);
-    const int* order = CV.order_of(chain, level);
-    const size_t vo = (size_t)chain * CV.vstride;
-    for (int i = blockIdx.x; i < count; i += gridDim.x) {
-        const int a = order[i];
-        if (a < 0) continue;
-        const double* s = src + vo + (size_t)BLD * a;
-        double* d = dst + vo + (size_t)BLD * a;
-        for (int e = threadIdx.x; e < BLD; e += blockDim.x) {
-            const int r = e / 36, c36 = e % 36;
-            d[kp_offset(r, c36 / 18, c36 % 18)] = s[e];
-        }
-    }
 }
 
 }  // namespace rsrec

@@ -25,12 +25,14 @@ namespace rsrec {
 __host__ __device__ constexpr int pk_col(int q, int l4) { return q < 8 ? 8 * (q >> 1) + 2 * l4 + (q & 1) : 32 + l4; }
 
 // fragment table of G (18x18 complex, column-major) for [X_re | X_im] * Ghat with the paired k order
-__device__ __forceinline__ void emit_rhs_frags_pk(const double2* M, double sign, double* out) {
+// ci: the vectors are in the CI layout (real column j of a row = (part j & 1, column j >> 1)); else LayoutRM (part j / 18, column j % 18)
+__device__ __forceinline__ void emit_rhs_frags_pk(const double2* M, double sign, double* out, int ci_layout) {
     for (int e = threadIdx.x; e < 27 * 64; e += blockDim.x) {
         const int l = e & 63, qf = e >> 6, q = qf / 3, f = qf % 3;
         const int ki = pk_col(q, l >> 4);
         const int ko = (f < 2) ? 16 * f + (l & 15) : 32 + (l & 3);
-        const int pi = ki / 18, ci = ki % 18, po = ko / 18, co = ko % 18;
+        const int pi = ci_layout ? (ki & 1) : ki / 18, ci = ci_layout ? (ki >> 1) : ki % 18;
+        const int po = ci_layout ? (ko & 1) : ko / 18, co = ci_layout ? (ko >> 1) : ko % 18;
         const double2 g = M[ci + 18 * co];
         const double v = (pi == po) ? g.x : (pi == 0 ? g.y : -g.y);
         out[e] = sign * v;
@@ -60,15 +62,6 @@ __device__ __forceinline__ void u3_load(U3Operands& o, const double* __restrict_
     o.y = base[off + 32 + l4];
 }
 
-// the same operands from a vector stored in the KP layout only: off = BLD * atom + 36 r (LayoutRM row reference), kpt = element map
-__device__ __forceinline__ void u3_load_kp(U3Operands& o, const double* __restrict__ base, unsigned off, int l4, const unsigned short* kpt) {
-    const unsigned blk = (off / BLD) * BLD;
-    const unsigned short* t = kpt + (off - blk) + 2 * l4;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) { o.x[qq].x = base[blk + t[8 * qq]]; o.x[qq].y = base[blk + t[8 * qq + 1]]; }
-    o.y = base[blk + kpt[(off - blk) + 32 + l4]];
-}
-
 template <int Q>
 __device__ __forceinline__ double u3_k(const U3Operands& o) { return Q < 8 ? ((Q & 1) ? o.x[Q >> 1].y : o.x[Q >> 1].x) : o.y; }
 
@@ -86,21 +79,13 @@ __device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr,
 
 // u_next = t' T1 + u_prev T2 + u_cur T3, written over u_prev; Gram partial of u_next.
 // tabs[chain][3][27*64]: T1 = Binv_n, T2 = -Binv_{n-1} B_n, T3 = -Binv_n A_n (paired-k fragment tables).
-// One wave per SIMD (the three tables live in registers); the next row tile's operands are fetched before the current
-// tile's MFMAs so each wave keeps ~14 KB of reads in flight.
-// KP = 1: u_next is also written in the k-pair layout the next level's SpMM (k_spmm5) reads.
-// KP = 2: the u vectors exist in the KP layout ONLY (ucur, uprev are KP vectors; t' stays LayoutRM): one block stream less.
-template <int KP>
+// One wave per SIMD (the three tables live in registers); the operands of the next two row tiles are in flight while the
+// current one is multiplied (~27 KB of reads per wave).  The kernel treats a block row as 36 reals in memory order: it serves
+// LayoutRM and CI vectors alike (the tables carry the column meaning); 3 block reads + 1 block write per atom-step.
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                 const double* __restrict__ ucur, double* uprev,
-                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/,
-                                                                double* ukp_all = nullptr) {
+                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/) {
     __shared__ double lds[MF_WAVES * 1296];
-    __shared__ unsigned short kpt[KP ? BLD : 1];          // LayoutRM element (36 r + c36) -> KP offset
-    if (KP) {
-        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
-        __syncthreads();
-    }
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,7 +95,6 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     const double* tv = tvec + vo;
     const double* uc = ucur + vo;
     double* up = uprev + vo;
-    double* uk = KP == 2 ? up : (KP ? ukp_all + vo : nullptr);
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     double T1[27], T2[27], T3[27];
     {
@@ -122,17 +106,15 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     Gm.zero();
     const int nbx = active_workgroups(ngroups);
     GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx);
-    // row tiles of this wave, flattened: tile it = (group w.g + (it / 9) * step, rows 16 (it % 9) .. +15).  The operands of
-    // tiles it + 1 and it + 2 are in flight while tile it is multiplied (one 512-register wave per SIMD: the reads in
-    // flight are what hides the HBM latency, ~27 KB per wave)
+    // row tiles of this wave, flattened: tile it = (group w.g + (it / 9) * step, rows 16 (it % 9) .. +15)
     const int ntile = (w.g < w.end) ? ((w.end - w.g + w.step - 1) / w.step) * 9 : 0;
     auto load_tile = [&](int it, U3Operands& a, U3Operands& c, U3Operands& p) {
         it = min(it, ntile - 1);
         const int g = w.g + (it / 9) * w.step;
         const RowRef ra = group_row(order + (size_t)g * GROUP, 16 * (it % 9) + l15, zero_block);
         u3_load(a, tv, ra.off, l4);
-        if (KP == 2) { u3_load_kp(c, uc, ra.off, l4, kpt); u3_load_kp(p, up, ra.off, l4, kpt); }
-        else { u3_load(c, uc, ra.off, l4); u3_load(p, up, ra.off, l4); }
+        u3_load(c, uc, ra.off, l4);
+        u3_load(p, up, ra.off, l4);
     };
     U3Operands ot, oc, op, nt, nc, np;
     if (ntile > 0) { load_tile(0, ot, oc, op); load_tile(1, nt, nc, np); }
@@ -150,19 +132,10 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
-            if (rs.valid) {
-                if (KP != 2) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
-                if (KP) {
-                    const unsigned blk = (rs.off / BLD) * BLD, e0 = rs.off - blk;      // block base, 36 r
-                    uk[blk + kpt[e0 + l15]] = ca[j]; uk[blk + kpt[e0 + 16 + l15]] = cb[j];
-                }
-            }
+            if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
         }
         const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
-        if (rr.valid) {
-            if (KP != 2) up[rr.off + 32 + l3] = cr;
-            if (KP) { const unsigned blk = (rr.off / BLD) * BLD; uk[blk + kpt[rr.off - blk + 32 + l3]] = cr; }
-        }
+        if (rr.valid) up[rr.off + 32 + l3] = cr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double f0 = ca[j], f1 = cb[j];
@@ -182,11 +155,11 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
 
 // G = sum u_n^H t'  ->  A_n = Binv_n G Binv_n (the coefficient, recursion.f90:1642), T3 = -Binv_n A_n
 __global__ __launch_bounds__(1024) void k_reduce_a_u(const double* __restrict__ partial, int nblk, double2* a_out, size_t astride,
-                                                    const double2* __restrict__ Bmats /*[chain][2][324]: B_n, Binv_n*/, double* tabs) {
+                                                    const double2* __restrict__ Bmats /*[chain][2][324]: B_n, Binv_n*/, double* tabs, int ci) {
     __shared__ double lds[1296];
     __shared__ double2 Gm[BLK], Bi[BLK], M1[BLK], M2[BLK];
     const int chain = blockIdx.x;
-    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds, ci);
     if (threadIdx.x < BLK) { Gm[threadIdx.x] = c; Bi[threadIdx.x] = Bmats[(size_t)chain * 2 * BLK + BLK + threadIdx.x]; }
     __syncthreads();
     matmul18(Gm, Bi, M1);            // G Binv
@@ -196,18 +169,18 @@ __global__ __launch_bounds__(1024) void k_reduce_a_u(const double* __restrict__ 
     if (threadIdx.x < BLK) a_out[chain * astride + threadIdx.x] = M2[threadIdx.x];
     matmul18(Bi, M2, M1);            // Binv A
     __syncthreads();
-    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 2) * 27 * 64);
+    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 2) * 27 * 64, ci);
 }
 
 // B_{n+1}^2 = sum u_{n+1}^H u_{n+1} (b2_b, recursion.f90:1931) -> B_{n+1}, Binv_{n+1} (:1937-1960);
 // tables for the next level: T1 = Binv_{n+1}, T2 = -Binv_n B_{n+1}
 __global__ __launch_bounds__(1024) void k_reduce_b_u(const double* __restrict__ partial, int nblk, double2* b2_out, size_t bstride, double2* Bmats,
-                                                    double* tabs, int* status) {
+                                                    double* tabs, int* status, int ci) {
     __shared__ double lds[1296];
     __shared__ Eig18Shared sh;
     __shared__ double2 Bn[BLK], Bin[BLK], Bold[BLK], M1[BLK];
     const int chain = blockIdx.x;
-    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds);
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds, ci);
     double2* Bout = Bmats + (size_t)chain * 2 * BLK;
     if (threadIdx.x < BLK) { b2_out[chain * bstride + threadIdx.x] = c; sh.A[threadIdx.x] = c; Bold[threadIdx.x] = Bout[BLK + threadIdx.x]; }
     __syncthreads();
@@ -221,18 +194,18 @@ __global__ __launch_bounds__(1024) void k_reduce_b_u(const double* __restrict__ 
     matmul18(Bold, Bn, M1);          // Binv_n B_{n+1}
     for (int e = threadIdx.x; e < BLK; e += blockDim.x) { Bout[e] = Bn[e]; Bout[BLK + e] = Bin[e]; }
     __syncthreads();
-    emit_rhs_frags_pk(Bin, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64);
-    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 1) * 27 * 64);
+    emit_rhs_frags_pk(Bin, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64, ci);
+    emit_rhs_frags_pk(M1, -1.0, tabs + ((size_t)chain * 3 + 1) * 27 * 64, ci);
 }
 
 // initial state of a chain: B_1 = Binv_1 = I, T1 = I, T2 = T3 = 0
-__global__ void k_uscheme_init(double2* Bmats, double* tabs) {
+__global__ void k_uscheme_init(double2* Bmats, double* tabs, int ci) {
     __shared__ double2 I[BLK];
     const int chain = blockIdx.x;
     for (int e = threadIdx.x; e < BLK; e += blockDim.x) I[e] = make_double2((e % NB) == (e / NB) ? 1.0 : 0.0, 0.0);
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * BLK; e += blockDim.x) Bmats[(size_t)chain * 2 * BLK + e] = I[e % BLK];
-    emit_rhs_frags_pk(I, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64);
+    emit_rhs_frags_pk(I, 1.0, tabs + ((size_t)chain * 3 + 0) * 27 * 64, ci);
     for (int e = threadIdx.x; e < 2 * 27 * 64; e += blockDim.x) tabs[((size_t)chain * 3 + 1) * 27 * 64 + e] = 0.0;
 }
 
@@ -242,21 +215,15 @@ __global__ void k_uscheme_init(double2* Bmats, double* tabs) {
 // The SpMM kernel leaves t = H psi1 in a vector; this kernel does everything after it in ONE pass over the active blocks:
 //   FIRST:  psi1 = (t - b psi0) / a                      ; G2 = sum psi0^H psi1                       (:2228-2236)
 //   else :  psi2 = ((t - b psi1) / a) * 2 - psi0         ; G1 = sum psi1^H psi1, G2 = sum psi2^H psi1 (:2548-2587)
-// in the reference's operation order.  The new vector is written in LayoutRM and, if KP, in the k-pair layout that
-// k_spmm5 reads.  The 18x18 complex reductions are real 36x36 Gram matrices with the stacked rows as MFMA K dimension
-// (same construction as k_mfma_adot); partial[chain][workgroup][2][1296].
+// in the reference's operation order, element-wise on rows of 36 reals: LayoutRM and CI vectors alike.  The 18x18 complex
+// reductions are real 36x36 Gram matrices with the stacked rows as MFMA K dimension (same construction as k_mfma_adot);
+// partial[chain][workgroup][2][1296].
 // ======================================================================================================================
-template <bool FIRST, bool KP>
+template <bool FIRST>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                const double* __restrict__ cur_all, const double* __restrict__ old_all,
-                                                               double* __restrict__ out_all, double a, double b, double* partial,
-                                                               double* __restrict__ okp_all = nullptr) {
+                                                               double* __restrict__ out_all, double a, double b, double* partial) {
     __shared__ double lds[MF_WAVES * 1296];
-    __shared__ unsigned short kpt[KP ? BLD : 1];
-    if (KP) {
-        for (int e = threadIdx.x; e < BLD; e += blockDim.x) kpt[e] = (unsigned short)kp_offset(e / 36, (e % 36) / 18, (e % 36) % 18);
-        __syncthreads();
-    }
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -267,7 +234,6 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
     const double* cu = cur_all + vo;
     const double* ol = FIRST ? nullptr : old_all + vo;
     double* out = out_all + vo;
-    double* okp = KP ? okp_all + vo : nullptr;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     GramAcc G1, G2;
     G1.zero(); G2.zero();
@@ -287,11 +253,6 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
             if (rk.valid) {
                 out[rk.off + l15] = n0; out[rk.off + 16 + l15] = n1;
                 if (lg == 0) out[rk.off + 32 + l3] = nr;
-                if (KP) {
-                    const unsigned blk = (rk.off / BLD) * BLD, e0 = rk.off - blk;
-                    okp[blk + kpt[e0 + l15]] = n0; okp[blk + kpt[e0 + 16 + l15]] = n1;
-                    if (lg == 0) okp[blk + kpt[e0 + 32 + l3]] = nr;
-                }
             }
             if (FIRST) {          // G2 = psi0hat^T psi1hat
                 G2.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, n0, G2.t00, 0, 0, 0);
@@ -331,7 +292,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
 // 36x36 Gram partials of k_mfma_cheb -> moments.  first: mu[1] = sum psi0^H psi1.  else: mu[2ll] = 2 d1 - mu[0],
 // mu[2ll+1] = 2 d2 - mu[1] (0-based moment index; recursion.f90:2591-2592) and the divergence test of :2594 / :2484.
 __global__ __launch_bounds__(1024) void k_reduce_cheb_mf(const double* __restrict__ partial, int nblk, int first, int ll, double2* mu, size_t mustride,
-                                                        int* status, int check_both) {
+                                                        int* status, int check_both, int ci) {
     __shared__ double img[2][1296];
     __shared__ double tr[2][BLK];
     const int chain = blockIdx.x, tid = threadIdx.x;
@@ -346,8 +307,9 @@ __global__ __launch_bounds__(1024) void k_reduce_cheb_mf(const double* __restric
     double2* m = mu + chain * mustride;
     if (tid < BLK) {
         const int cp = tid % NB, cc = tid / NB;
-        const double2 d1 = make_double2(img[0][36 * cp + cc] + img[0][36 * (18 + cp) + 18 + cc], img[0][36 * cp + 18 + cc] - img[0][36 * (18 + cp) + cc]);
-        const double2 d2 = make_double2(img[1][36 * cp + cc] + img[1][36 * (18 + cp) + 18 + cc], img[1][36 * cp + 18 + cc] - img[1][36 * (18 + cp) + cc]);
+        const int rp = gram_col(0, cp, ci), ip = gram_col(1, cp, ci), rc = gram_col(0, cc, ci), ic = gram_col(1, cc, ci);
+        const double2 d1 = make_double2(img[0][36 * rp + rc] + img[0][36 * ip + ic], img[0][36 * rp + ic] - img[0][36 * ip + rc]);
+        const double2 d2 = make_double2(img[1][36 * rp + rc] + img[1][36 * ip + ic], img[1][36 * rp + ic] - img[1][36 * ip + rc]);
         if (first) {
             m[BLK + tid] = d2;
             tr[0][tid] = 0.0; tr[1][tid] = 0.0;

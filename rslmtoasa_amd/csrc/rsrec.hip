@@ -84,7 +84,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_kp_only = 0, opt_side = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -340,7 +340,6 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
-    else if (!strcmp(key, "kp_only")) h->opt_kp_only = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
@@ -790,14 +789,14 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     int nvec = MFMA ? 4 : (hoh ? 3 : 2);
     const bool three_term = MFMA && !hoh && h->opt_post != 1 && !h->opt_fuse && h->opt_three;
     const bool u_scheme = three_term && h->opt_three == 2 && h->opt_wps != 2;
-    // SpMM input in the k-pair layout (k_spmm5): the large-launch kernel; small launches keep the cooperative k_spmm4<4>
-    // (spmm5 = 2 forces it)
+    // large launches: k_spmm5 with every vector in the CI layout; small launches keep the cooperative k_spmm4<4> on LayoutRM
+    // (spmm5 = 2 forces k_spmm5)
     const bool use_kp = u_scheme && h->s5_built && h->opt_spmm4 != 0 &&
                         (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
     // hoh on the un-normalised scheme: both SpMM passes in k_spmm5 (first pass writes KP, second pass adds the on-site
     // e_nu + l.s term from psi through its extra slot), then the same post-hop kernels as without hoh
     const bool u_hoh = MFMA && hoh && h->opt_post != 1 && h->opt_three == 2 && h->opt_wps != 2 && h->s5_built && h->opt_spmm5 >= 1 && h->opt_spmm4 != 0;
-    if (use_kp || u_hoh) nvec = 5;
+    const int ci = (use_kp || u_hoh) ? 1 : 0;                 // vectors of this call are CI (else LayoutRM / LayoutCM)
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -867,16 +866,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
         psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (the three-term scheme swaps them every level)
-        k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        else k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
-        if (u_scheme || u_hoh) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags);
-        double* ukp = (use_kp || u_hoh) ? h->d_vec[4].as<double>() : nullptr;
-        if (use_kp || u_hoh) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, psi, ukp);
-        // kp_only (option, off): the u vectors live in the KP layout only (psi / t2 then name the two KP buffers; t' = hpsi stays
-        // LayoutRM): the orthogonalisation kernel writes one copy of u_next instead of two.  Measured 7 % SLOWER post-hop
-        // (4.70 vs 4.40 ms per level): the 8-byte gathers of the u operands from the KP layout cost more than the saved stream.
-        const bool kp_only = (use_kp || u_hoh) && h->opt_kp_only;
-        if (kp_only) psi = ukp;
+        if (u_scheme || u_hoh) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags, ci);
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         // u-scheme: H u_{n+1} does not need B_{n+1}, so the reduction of sum u_{n+1}^H u_{n+1} and its 18x18 eigen-solve (one
@@ -898,7 +891,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             }
             int n2 = nwg;
             const double* p2 = presum(h, gp_b, nb, n2, 1296, st, side ? 1 : 0);
-            k_reduce_b_u<<<nb, 1024, 0, st>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags, h->d_status.as<int>());
+            k_reduce_b_u<<<nb, 1024, 0, st>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags, h->d_status.as<int>(), ci);
             if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); b_pending = true; }
             return RSREC_OK;
         };
@@ -928,7 +921,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), kp_only ? psi : ukp, hpsi);
+                    else if (use_kp) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), psi, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
                     tvec = hpsi;
@@ -936,21 +929,18 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         if (u_scheme) {
                             // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
                             const dim3 gl = level_grid(h, grid_mf, lv_final);
-                            if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                            else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                            k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                             { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                               rc = wait_b_level(); if (rc) return rc;
-                              k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                            if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                            else if (use_kp) k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b, ukp);
-                            else k_mfma_orth3<0><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                              k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
+                            k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
                             rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                             std::swap(psi, t2);
                             hop_ev.emplace_back(e0, e1);
                             h->n_hop_launch += 1;
                             continue;
                         }
-                        k_mfma_adot<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                         k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
                         if (three_term) {
                             // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
@@ -976,20 +966,18 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     e1 = next_event(h);
                 }
             } else if (u_hoh) {
-                double* hkp = pmn;                       // the pmn buffer is free in the u-scheme: KP copy of h psi
+                double* hps = pmn;                       // the pmn buffer is free in the u-scheme: h psi of the first pass
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), kp_only ? psi : ukp, hkp);
+                k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), psi, hps);
                 SD.level = lv_final;
-                k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, hpsi, kp_only ? psi : ukp);
+                k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hps, hpsi, psi);
                 e1 = next_event(h);
-                if (kp_only) k_mfma_adot<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                else k_mfma_adot<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                   rc = wait_b_level(); if (rc) return rc;
-                  k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags); }
-                if (kp_only) k_mfma_orth3<2><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                else k_mfma_orth3<1><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b, ukp);
+                  k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
+                k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
                 rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                 std::swap(psi, t2);
                 hop_ev.emplace_back(e0, e1);
@@ -1274,7 +1262,8 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     // hoh always takes k_spmm5 (its second pass folds the on-site terms in); plain Chebyshev only for large launches
     const bool use_kp = mf_cheb && s5_ok &&
                         (hoh || h->opt_spmm5 == 2 || (h->opt_spmm4 < 0 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096));
-    const int nvec = MFMA ? (hoh ? (mf_cheb ? 6 : 5) : (use_kp ? 5 : 4)) : (hoh ? 4 : 3);
+    const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
+    const int ci = use_kp ? 1 : 0;                              // vectors of this call are CI (else LayoutRM / LayoutCM)
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -1339,11 +1328,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         double* tmp = h->d_vec[3].as<double>();
         double* tmp2 = h->d_vec[4].as<double>();
         const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
-        k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+        else k_seed<L><<<nb, 64, 0, h->stream>>>(p0, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(mu, mstride, h->d_seedcoef.as<double>() + (size_t)nb * nseed * 2);   // mu_1 (cheb_0th_mom :2157)
-        double* vkp = use_kp ? tmp2 : nullptr;                  // k-pair copy of the vector the next SpMM reads
-        double* hkp = (use_kp && hoh) ? h->d_vec[5].as<double>() : nullptr;   // hoh: k-pair copy of h psi (first pass -> second pass)
-        if (use_kp) k_rm_to_kp<<<dim3(8, nb), 256, 0, h->stream>>>(CV, 0, p0, vkp);
+        double* hps = (use_kp && hoh) ? tmp2 : nullptr;         // hoh: h psi of the first pass
         const dim3 grid(nblk, nb);
         for (int t = 1; t <= napply; ++t) {      // t = 1: first moment; t >= 2: recursion step ll = t-1
             const bool first = (t == 1);
@@ -1359,23 +1347,18 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
                 if (hoh) {
                     SD.level = 2 * t - 1;
-                    k_spmm5<true, false><<<s5_grid(h, grid_mf, 2 * t - 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, hkp);
+                    k_spmm5<false><<<s5_grid(h, grid_mf, 2 * t - 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), src, hps);
                     SD.level = lv_final;
-                    k_spmm5<false, true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hkp, tmp, vkp);
-                } else if (use_kp) k_spmm5<false, false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), vkp, tmp);
+                    k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hps, tmp, src);
+                } else if (use_kp) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), src, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += hoh ? 2 : 1;
                 double* gp = h->d_partial.as<double>();
                 if (red_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); red_pending = false; }   // gp is free again
-                if (first) {
-                    if (use_kp) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp, vkp);
-                    else k_mfma_cheb<true, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
-                } else {
-                    if (use_kp) k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp, vkp);
-                    else k_mfma_cheb<false, false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
-                }
+                if (first) k_mfma_cheb<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
+                else k_mfma_cheb<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 hipStream_t rs = h->stream;
                 if (side) {
                     HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
@@ -1383,7 +1366,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                     rs = h->side_stream;
                 }
                 int n2 = gl.x; const double* gp2 = presum(h, gp, nb, n2, 2 * 1296, rs, side ? 1 : 0);
-                k_reduce_cheb_mf<<<nb, 1024, 0, rs>>>(gp2, n2, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0);
+                k_reduce_cheb_mf<<<nb, 1024, 0, rs>>>(gp2, n2, first ? 1 : 0, t - 1, mu, mstride, h->d_status.as<int>(), nseed > 1 ? 1 : 0, ci);
                 if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); red_pending = true; }
                 if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
                 continue;

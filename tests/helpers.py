@@ -11,7 +11,7 @@ SCALARS = ("kk", "nmax", "ntype", "nrec", "lld", "nsp", "hoh", "kind", "nslots",
 
 BLOCK_CASES = ["bccFe_nsp2_block", "bccFe_nsp2_block_hoh", "bccFe_nsp4_block", "B2FeCo_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
 CHEB_CASES = ["bccFe_nsp2_cheb", "bccFe_nsp2_cheb_hoh", "fccCu001_cheb"]
-SCALAR_CASES = ["bccFe_nsp1_lanczos"]
+SCALAR_CASES = ["bccFe_nsp1_lanczos", "fccCu001_nsp1_lanczos", "B2FeCo_nsp1_lanczos"]
 SUPERCELL_CASES = ["sc_4x4x8_block", "sc_4x4x8_block_hoh", "sc_4x4x8_cheb", "sc_22_block"]
 PAIR_CASES = ["sc_4x4x8_block_ij", "sc_4x4x8_cheb_ij", "sc_4x4x8_cheb_ij_hoh"]
 
@@ -28,8 +28,73 @@ def load_golden(name):
     return d
 
 
+def level_errors(x, ref):
+    """Relative max-norm error of every 18x18 coefficient matrix on its own: arrays are (18, 18, level[, site]) as the reference
+    stores a_b / b2_b / mu_n; entry [level, site] = max|x - ref| / max|ref| over that one matrix.  A matrix the reference holds as
+    exact zeros (a_b(:,:,lld), recursion.f90:1836) must be reproduced exactly (error 0, else inf)."""
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape, (x.shape, ref.shape)
+    if x.ndim <= 2:
+        x, ref = x.reshape(x.shape + (1,) * (3 - x.ndim)), ref.reshape(ref.shape + (1,) * (3 - ref.ndim))
+    d = np.abs(x - ref).max(axis=(0, 1))
+    r = np.abs(ref).max(axis=(0, 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(r > 0, d / r, np.where(d > 0, np.inf, 0.0))
+
+
 def rel_err(x, ref):
-    return float(np.abs(np.asarray(x) - np.asarray(ref)).max() / np.abs(ref).max())
+    """Worst per-matrix relative error (see level_errors): a small late coefficient is held to the same RELATIVE bar as the
+    large early ones (a global max-norm ratio would let b2_b(:,:,1) = I set the scale for every level)."""
+    return float(np.max(level_errors(x, ref)))
+
+
+def rel_err_rows(x, ref):
+    """The same for the scalar recursion's tables a / b2 (level, orbital, site): one number per (level, site) over the 18 orbital
+    chains.  Entries the reference leaves as NaN or zero must match exactly."""
+    x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert x.shape == ref.shape
+    worst = 0.0
+    for idx in np.ndindex(ref.shape[0], *ref.shape[2:]):
+        a, b = x[(idx[0], slice(None)) + idx[1:]], ref[(idx[0], slice(None)) + idx[1:]]
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            return float("inf")
+        a, b = a[~np.isnan(b)], b[~np.isnan(b)]
+        if b.size == 0:
+            continue
+        scale = np.abs(b).max()
+        err = np.abs(a - b).max()
+        worst = max(worst, err / scale if scale > 0 else (np.inf if err > 0 else 0.0))
+    return float(worst)
+
+
+def spread_tolerance(name, key, gold, k=8.0):
+    """Per-level bar for the ill-conditioned 128-atom LL = 30 cases (540 block-Lanczos vectors in a 2304-dimensional space: from
+    level 26 on rounding is amplified ~10x per level IN THE REFERENCE ITSELF).  tests/golden/<name>_spread.npz holds the compiled
+    reference's own coefficients at 1, 2 and 8 OpenMP threads (the summation order of its `omp reduction` sums, recursion.f90:1638,
+    depends on the thread count): they differ from each other by 8e-13 at level 27 and 1e-10 at level 30.
+    Returns tol[level, site] = max(RTOL, k x the reference's spread at that level)."""
+    with np.load(os.path.join(GOLD, name + "_spread.npz"), allow_pickle=False) as sp:
+        runs = [gold] + [sp["%s_t%d" % (key, t)] for t in sp["threads"]]
+    spread = np.max([level_errors(x, y) for i, x in enumerate(runs) for y in runs[i + 1:]], axis=0)
+    return np.maximum(RTOL, k * spread)
+
+
+def assert_within_reference_spread(name, key, mine, gold):
+    tol = spread_tolerance(name, key, gold)
+    err = level_errors(mine, gold)
+    assert np.all(err <= tol), (name, key, np.argwhere(err > tol).tolist(), float(err.max()))
+    assert np.all(tol[:24] == RTOL)          # the relaxation only ever touches the last levels
+
+
+def load_golden_with_inputs(name):
+    """Fixtures that hold outputs only (`inputs_from` names the fixture with the identical inputs) merged with those inputs."""
+    g = load_golden(name)
+    if "inputs_from" in g:
+        base = load_golden(str(g["inputs_from"]))
+        for k in ("nn", "iz", "irec", "ee", "lsham", "eeo", "enim", "hall", "hallo", "kk", "nmax", "ntype", "nrec", "nsp", "hoh", "nslots"):
+            if k in base and k not in g:
+                g[k] = base[k]
+    return g
 
 
 def problem_dict(g):

@@ -3,10 +3,13 @@
 Bar (BASELINE.json north_star): recursion coefficients / moments within 1e-10 relative of the reference.
 All arithmetic is FP64; differences come only from summation order (MFMA / tree reductions vs BLAS).
 """
+import os
+
 import numpy as np
 import pytest
 
-from helpers import (BLOCK_CASES, CHEB_CASES, PAIR_CASES, RTOL, SCALAR_CASES, load_golden, objects_from, problem_dict, rel_err, supercell_problem)
+from helpers import (assert_within_reference_spread, BLOCK_CASES, CHEB_CASES, GOLD, PAIR_CASES, RTOL, SCALAR_CASES, load_golden, load_golden_with_inputs, objects_from,
+                     problem_dict, rel_err, rel_err_rows, supercell_problem)
 from rslmtoasa_amd.lattice import spread_sites
 from rslmtoasa_amd.recursion import Recursion
 
@@ -68,8 +71,19 @@ def test_scalar_lanczos_golden(name):
     g = load_golden(name)
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], llsp=g["a"].shape[0])
     rec.recur()
-    assert rel_err(rec.a[:, :, :, 0], g["a"]) < RTOL
-    assert rel_err(rec.b2[:, :, :, 0], g["b2"]) < RTOL
+    assert rel_err_rows(rec.a[:, :, :, 0], g["a"]) < RTOL
+    assert rel_err_rows(rec.b2[:, :, :, 0], g["b2"]) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("kernels", BLOCK_VARIANTS)
+def test_chebyshev_surface_full_depth(kernels):
+    """SURVEY C4 at its real depth: fccCu(001), three atom types, two sites, lld = 50 (102 moments) against the compiled reference."""
+    g = load_golden_with_inputs("fccCu001_cheb50")
+    rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], emin=g["emin"], emax=g["emax"])
+    select_kernels(rec, kernels)
+    rec.chebyshev_recur()
+    assert rel_err(rec.mu_n[:, :, :, : g["nrec"]], g["mu_n"]) < RTOL
     rec.close()
 
 
@@ -91,13 +105,9 @@ def test_config0_supercell_block(name, kernels):
     rec.set_option("kernels", kernels)
     rec.recur_b()
     n = len(g["irec"])
-    # 18*30 = 540 Lanczos vectors in a 2304-dimensional space: the late coefficients amplify rounding (the CPU
-    # restatement itself differs from the reference by 4e-11 here), so the bar is applied to the first 20 levels
-    # at 1e-10 and to all 30 at 1e-8.
-    assert rel_err(rec.a_b[:, :, :20, :n], g["a_b"][:, :, :20]) < RTOL
-    assert rel_err(rec.b2_b[:, :, :20, :n], g["b2_b"][:, :, :20]) < RTOL
-    assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < 1e-8
-    assert rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]) < 1e-8
+    # per level: 1e-10 wherever the reference agrees with itself, else 8x the reference's own thread-count spread (helpers.spread_tolerance)
+    assert_within_reference_spread(name, "a_b", rec.a_b[:, :, :, :n], g["a_b"])
+    assert_within_reference_spread(name, "b2_b", rec.b2_b[:, :, :, :n], g["b2_b"])
     rec.close()
 
 
@@ -170,7 +180,7 @@ def test_config2_size_1e5_atoms():
 
 
 @pytest.mark.parametrize("opts", [{"three_term": 0}, {"three_term": 1}, {"three_term": 2, "spmm4": 1}, {"three_term": 2, "spmm4": 4},
-                                  {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}, {"spmm5": 2, "kp_only": 1}])
+                                  {"three_term": 2, "spmm4": 0}, {"three_term": 1, "spmm4": 0}, {"fuse": 1, "spmm4": 0}, {"spmm5": 2, "side_stream": 0}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """The alternative pipelines kept in the library (reference order, normalised three-term, un-normalised; each SpMM kernel)
