@@ -198,20 +198,20 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
 
 
 def ldos_stage(rec, gz, ene, nloc, step_s):
-    """zsqr + terminator + Green function + LDOS reduction for the sites of one step (second call = steady state of an SCF loop)."""
-    import numpy as np
+    """The LDOS stage for the sites of one step, on the device from the resident coefficients: zsqr + get_terminf + bgreen + the
+    reduction of bands.f90:258-268 (rsrec_block_ldos).  Second call = steady state of an SCF loop (buffers exist)."""
     from rslmtoasa_amd.green import Green
-    a_inf = np.repeat(gz["a_inf"][:, :, :1], nloc, axis=2)
-    b_inf = np.repeat(gz["b_inf"][:, :, :1], nloc, axis=2)
     gr = Green(rec, ene)
     for _ in range(2):
         t0 = time.perf_counter()
-        rec.zsqr()
-        gr.block_green(a_inf, b_inf, nsites=nloc)
+        r = gr.block_ldos()
         tg = time.perf_counter() - t0
     tmg = rec.timing()
-    return {"wall_ms": tg * 1e3, "kernel_ms": tmg["hop_ms"], "energies": len(ene), "sites_per_s_recursion_plus_ldos": nloc / (step_s + tg),
-            "note": "zsqr + rsrec_block_green (green.f90:1191 bgreen) for the sites of one step incl. the g0 download; terminator from the fixture; not in `value`"}
+    assert (r["dosial"] == r["dosial"]).all()
+    return {"wall_ms": tg * 1e3, "green_kernel_ms": tmg["hop_ms"], "zsqr_terminator_reduction_ms": tmg["rest_ms"], "energies": len(ene),
+            "sites_per_s_recursion_plus_ldos": nloc / (step_s + tg),
+            "note": "rsrec_block_ldos: zsqr + get_terminf + bgreen + LDOS reduction for the sites of one step, all on the device; "
+                    "dtot/dosia/dosial (18 doubles per site and energy) come back; not in `value`"}
 
 
 def profiled_traffic(workload_key, kernel):

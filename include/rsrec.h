@@ -105,12 +105,33 @@ int rsrec_zsqr(rsrec_t *h, int nmat, double *b2_b);
  *   ene    : real (nen) energy mesh, energy%ene(1:channels_ldos+10) (energy.f90:205-207)
  *   eta    : complex broadening added to E on the diagonal (block_green: 0; block_green_eta: the caller's eta)
  *   sym_term: control%sym_term (orbital-independent terminator, green.f90:1268-1277)
- *   a_inf, b_inf : real (18,18,nsites) from recursion%get_terminf (recursion.f90:2092; stays on the CPU)
+ *   a_inf, b_inf : real (18,18,nsites) from recursion%get_terminf (recursion.f90:2092) or rsrec_terminator
  *   a_b    : complex (18,18,lld,nsites) as returned by rsrec_block_lanczos
  *   b_sqrt : complex (18,18,lld,nsites) = b2_b AFTER rsrec_zsqr (self.f90:829 calls zsqr before block_green)
  *   g0     : complex (18,18,nen,nsites) out */
 int rsrec_block_green(rsrec_t *h, int nsites, int lld, int nen, const double *ene, double eta_re, double eta_im, int sym_term,
                       const double *a_inf, const double *b_inf, const double *a_b, const double *b_sqrt, double *g0);
+
+/* Band-dependent terminator coefficients of the block recursion.  Replaces recursion%get_terminf (recursion.f90:2092-2135) with
+ * get_cinf (:2030-2086), bpopt (:3540-3580: Beer-Pettifor iteration) and emami (:3589-3700: extreme eigenvalues of the tridiagonal
+ * chain by Sturm bisection): one GPU thread per matrix element and site, the reference's operations in the reference's order.
+ *   a_b    : complex (18,18,lld,nsites);  b_sqrt : complex (18,18,lld,nsites) = b2_b after zsqr (self.f90:829)
+ *   a_inf, b_inf : real (18,18,nsites) out;  a_inf0, b_inf0 : real (nsites) out (mean diagonals; may be NULL) */
+int rsrec_terminator(rsrec_t *h, int nsites, int lld, const double *a_b, const double *b_sqrt, double *a_inf, double *b_inf,
+                     double *a_inf0, double *b_inf0);
+
+/* The whole LDOS stage for the sites of the LAST rsrec_block_lanczos call, from the coefficients that call left on the device
+ * (nothing is uploaded but the energy mesh): zsqr (recursion.f90:1980) -> get_terminf (:2092) -> green%bgreen (green.f90:1191,
+ * eta / sym_term as in rsrec_block_green) -> the reduction of bands%calculate_fermi (bands.f90:258-268),
+ *   dosial(ia,j,i) = -Im g0(j,j,i,ia)/pi,  dosia(ia,i) = sum_j dosial,  dtot(i) = sum_ia dosia   (summed in the reference's order).
+ * Outputs are the zero-padded images the reference all-reduces over the ranks (bands.f90:271-274): this rank's sites are
+ * site_offset+1 .. site_offset+nsites of nsites_total, every other site is zero.
+ *   dtot : real (nen);  dosia : real (nsites_total, nen);  dosial : real (nsites_total, 18, nen)  -- HOST or DEVICE memory (all three
+ *   alike, detected): device buffers are written in place and can be handed to the collective without a host round trip.
+ *   a_inf, b_inf : real (18,18,nsites) host out, the terminators used (may be NULL).
+ * 18 doubles per site and energy leave the GPU instead of the 648 of g0. */
+int rsrec_block_ldos(rsrec_t *h, int nen, const double *ene, double eta_re, double eta_im, int sym_term, int site_offset, int nsites_total,
+                     double *dtot, double *dosia, double *dosial, double *a_inf, double *b_inf);
 
 /* Green function from the Chebyshev moments.  Replaces green%chebyshev_green (green.f90:1030-1108) for the sites of this rank:
  *   g0(:,:,ie,site) = sum_i mu_n(:,:,i,site) k_i (-i) exp(-i (i-1) acos w_ie) / sqrt(a^2 - (e_ie - b)^2),  w = (e - b)/a,

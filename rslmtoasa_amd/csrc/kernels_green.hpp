@@ -199,9 +199,13 @@ __device__ __forceinline__ void green_fetch(double2 (&an)[2][3], double2 (&bn)[6
 #ifndef GREEN_WAVES_PER_SIMD
 #define GREEN_WAVES_PER_SIMD 3
 #endif
+// LDOS = true: only Im g0(j,j) leaves the kernel, gim[site][nen][18] (the LDOS stage needs nothing else: bands.f90:258-268), 144 B
+// per (site, energy) instead of 5184 B.
+template <bool LDOS>
 __global__ __launch_bounds__(GREEN_WAVES * 64, GREEN_WAVES_PER_SIMD) void k_block_green(int lld, int nen, const double* __restrict__ ene, double eta_re, double eta_im, int sym_term,
                                                                  const double* __restrict__ a_inf, const double* __restrict__ b_inf,
-                                                                 const double2* __restrict__ a_b, const double2* __restrict__ b_sqrt, double2* __restrict__ g0) {
+                                                                 const double2* __restrict__ a_b, const double2* __restrict__ b_sqrt, double2* __restrict__ g0,
+                                                                 double* __restrict__ gim = nullptr) {
     __shared__ GreenLds lds[GREEN_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ei = blockIdx.x * GREEN_WAVES + wave, site = blockIdx.y;
@@ -309,6 +313,10 @@ __global__ __launch_bounds__(GREEN_WAVES * 64, GREEN_WAVES_PER_SIMD) void k_bloc
             for (int c = 0; c < 3; ++c) L.M[(2 * ig + rr) + NB * (3 * jg + c)] = q[rr][c];
     }
     wave_sync();
+    if (LDOS) {
+        if (lane < NB) gim[((size_t)site * nen + ei) * NB + lane] = L.M[lane * (NB + 1)].y;
+        return;
+    }
     double2* out = g0 + ((size_t)site * nen + ei) * BLK;
 #pragma unroll
     for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) out[el] = L.M[el]; }

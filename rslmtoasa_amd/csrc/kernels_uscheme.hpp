@@ -53,22 +53,24 @@ __device__ __forceinline__ void matmul18(const double2* A, const double2* B, dou
     }
 }
 
-struct U3Operands { double2 x[4]; double y; };
+struct U3Operands { double2 x[4]; double2 y; };           // y: columns 32 + 2 (l4 >> 1), + 1 (the lane uses member l4 & 1)
 
 __device__ __forceinline__ void u3_load(U3Operands& o, const double* __restrict__ base, unsigned off, int l4) {
     const double2* p = reinterpret_cast<const double2*>(base + off + 2 * l4);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) o.x[qq] = p[4 * qq];        // columns 8 qq + 2 l4, +1
-    o.y = base[off + 32 + l4];
+    // the ninth k-step's column 32 + l4 as one more 16-byte load (all five loads of an operand set have the same shape: an 8-byte
+    // load here made the register allocator recycle its destination pair as an address temporary -> a vmcnt(0) in the tile loop)
+    o.y = *reinterpret_cast<const double2*>(base + off + 32 + 2 * (l4 >> 1));
 }
 
 template <int Q>
-__device__ __forceinline__ double u3_k(const U3Operands& o) { return Q < 8 ? ((Q & 1) ? o.x[Q >> 1].y : o.x[Q >> 1].x) : o.y; }
+__device__ __forceinline__ double u3_k(const U3Operands& o, bool odd) { return Q < 8 ? ((Q & 1) ? o.x[Q >> 1].y : o.x[Q >> 1].x) : (odd ? o.y.y : o.y.x); }
 
-__device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr, const U3Operands& o, const double (&T)[27]) {
+__device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr, const U3Operands& o, const double (&T)[27], bool odd) {
 #define U3_STEP(Q)                                                                              \
     {                                                                                           \
-        const double a = u3_k<Q>(o);                                                            \
+        const double a = u3_k<Q>(o, odd);                                                          \
         ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[3 * (Q) + 0], ca, 0, 0, 0);              \
         cb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[3 * (Q) + 1], cb, 0, 0, 0);              \
         cr = __builtin_amdgcn_mfma_f64_4x4x4f64(a, T[3 * (Q) + 2], cr, 0, 0, 0);                \
@@ -108,33 +110,53 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx);
     // row tiles of this wave, flattened: tile it = (group w.g + (it / 9) * step, rows 16 (it % 9) .. +15)
     const int ntile = (w.g < w.end) ? ((w.end - w.g + w.step - 1) / w.step) * 9 : 0;
-    auto load_tile = [&](int it, U3Operands& a, U3Operands& c, U3Operands& p) {
+    // The atoms of a row tile come from the order list through SCALAR loads: a tile of 16 stacked rows touches at most two
+    // consecutive atoms of its group, (16 mt) / 18 and the next one, and the tile index is wave-uniform.  (A per-lane vector load of
+    // the atom index put a dependent load + s_waitcnt vmcnt(0) in front of every operand prefetch and every store group: the
+    // prefetched tiles were drained before the next ones were issued -- 44 % of the wave cycles in s_waitcnt.)
+    struct TileAtoms { int s0, a_lo, a_hi; };
+    auto tile_atoms = [&](int it) {
         it = min(it, ntile - 1);
-        const int g = w.g + (it / 9) * w.step;
-        const RowRef ra = group_row(order + (size_t)g * GROUP, 16 * (it % 9) + l15, zero_block);
+        const int* __restrict__ grp = order + (size_t)(w.g + (it / 9) * w.step) * GROUP;
+        TileAtoms t;
+        t.s0 = (16 * (it % 9)) / 18;
+        t.a_lo = grp[t.s0];
+        t.a_hi = grp[min(t.s0 + 1, GROUP - 1)];
+        return t;
+    };
+    auto tile_row = [&](const TileAtoms& t, int rho) {          // rho: stacked row inside the group, 16 mt <= rho < 16 mt + 16
+        const bool hi = rho >= 18 * (t.s0 + 1);
+        const int a = hi ? t.a_hi : t.a_lo;
+        RowRef R;
+        R.valid = a >= 0;
+        R.off = (unsigned)BLD * (unsigned)(R.valid ? a : zero_block) + 36u * (unsigned)(rho - 18 * (t.s0 + (hi ? 1 : 0)));
+        return R;
+    };
+    auto load_tile = [&](int it, U3Operands& a, U3Operands& c, U3Operands& p) {
+        const TileAtoms t = tile_atoms(it);
+        const RowRef ra = tile_row(t, 16 * (min(it, ntile - 1) % 9) + l15);
         u3_load(a, tv, ra.off, l4);
         u3_load(c, uc, ra.off, l4);
         u3_load(p, up, ra.off, l4);
     };
-    U3Operands ot, oc, op, nt, nc, np;
-    if (ntile > 0) { load_tile(0, ot, oc, op); load_tile(1, nt, nc, np); }
-#pragma unroll 1
-    for (int it = 0; it < ntile; ++it) {
-        const int* grp = order + (size_t)(w.g + (it / 9) * w.step) * GROUP;
+    // Three operand sets rotate through the roles (current, next, next-but-one) by NAME: the loop is unrolled three times, so a
+    // set is never copied while its loads are in flight (a register copy of a load target waits for the load -- the rotating
+    // copies of round 1 cut the effective prefetch distance to one tile: 38 % of the wave cycles sat in s_waitcnt,
+    // profiles/r02b_c2_sq_pmc.txt).  Loads of tile it + 2 are issued before the MFMAs of tile it.
+    auto compute_tile = [&](int it, const U3Operands& ot, const U3Operands& oc, const U3Operands& op) {
+        const TileAtoms ta = tile_atoms(it);
         const int mt = it % 9;
-        U3Operands ft, fc, fp;
-        load_tile(it + 2, ft, fc, fp);
         double4_t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
         double cr = 0.0;
-        u3_mac(ca, cb, cr, ot, T1);
-        u3_mac(ca, cb, cr, op, T2);
-        u3_mac(ca, cb, cr, oc, T3);
+        u3_mac(ca, cb, cr, ot, T1, l4 & 1);
+        u3_mac(ca, cb, cr, op, T2, l4 & 1);
+        u3_mac(ca, cb, cr, oc, T3, l4 & 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const RowRef rs = group_row(grp, 16 * mt + l4 + 4 * j, zero_block);
+            const RowRef rs = tile_row(ta, 16 * mt + l4 + 4 * j);
             if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
         }
-        const RowRef rr = group_row(grp, 16 * mt + 4 * lg + l4, zero_block);
+        const RowRef rr = tile_row(ta, 16 * mt + 4 * lg + l4);
         if (rr.valid) up[rr.off + 32 + l3] = cr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -147,8 +169,29 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
             Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
             Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
         }
-        ot = nt; oc = nc; op = np;
-        nt = ft; nc = fc; np = fp;
+    };
+    U3Operands at, ac, ap, bt, bc, bp, ct, cc, cp;
+    if (ntile > 0) { load_tile(0, at, ac, ap); load_tile(1, bt, bc, bp); }
+#pragma unroll 1
+    for (int it = 0; it < ntile; it += 3) {
+        // (the scheduling fences keep every use of a freshly issued operand set -- even the lane select of its ninth k-step --
+        //  below the fence of the tile that consumes it: hipcc otherwise hoists such uses to the load and drains the queue there)
+        load_tile(it + 2, ct, cc, cp);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile(it, at, ac, ap);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < ntile) {
+            load_tile(it + 3, at, ac, ap);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(it + 1, bt, bc, bp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it + 2 < ntile) {
+            load_tile(it + 4, bt, bc, bp);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(it + 2, ct, cc, cp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }

@@ -30,6 +30,7 @@
 #include "kernels_spmm5.hpp"
 #include "kernels_uscheme.hpp"
 #include "kernels_green.hpp"
+#include "kernels_ldos.hpp"
 
 using namespace rsrec;
 
@@ -80,6 +81,7 @@ struct rsrec_handle {
     int s5_built = 0;
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
+    DevBuf d_bsqrt, d_term, d_gim, d_ldos;   // LDOS stage on resident coefficients: sqrt(B^2), terminators, Im g0_jj, output images
     void* pin = nullptr;              // pinned host staging buffer: every per-call transfer goes through it (see xfer_*)
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
@@ -303,7 +305,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+    DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_partial2, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
@@ -1191,13 +1193,130 @@ extern "C" int rsrec_block_green(rsrec_t* h, int nsites, int lld, int nen, const
         XFER(xfer_h2d(h, d_bi, b_inf + (size_t)u0 * BLK, (size_t)nu * tbytes));
         XFER(green_pipeline(h, nu, gbytes, g0 + (size_t)u0 * nen * BLK * 2, [&](int s0, int ns, char* out) {
             const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, ns);
-            k_block_green<<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai + (size_t)s0 * BLK, d_bi + (size_t)s0 * BLK,
+            k_block_green<false><<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai + (size_t)s0 * BLK, d_bi + (size_t)s0 * BLK,
                                                                     d_ab + (size_t)s0 * lld * BLK, d_bs + (size_t)s0 * lld * BLK, reinterpret_cast<double2*>(out));
         }));
     }
     hipEvent_t ev1 = next_event(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->t_total_ms = ev_ms(ev0, ev1);
+    return RSREC_OK;
+}
+
+namespace {
+
+// get_terminf for n sites on the device: a_inf, b_inf [site][324], optional means
+int launch_terminator(rsrec_t* h, int n, int lld, const double2* d_ab, const double2* d_bs, double* d_ainf, double* d_binf) {
+    if (lld < 2) return fail(h, RSREC_ERR_ARG, "terminator needs lld >= 2");
+    // one LDS column of 2 * lld doubles per thread
+    int T = 64;
+    while (T > 8 && (size_t)2 * lld * T * sizeof(double) > (size_t)128 * 1024) T >>= 1;
+    const size_t lds = (size_t)2 * lld * T * sizeof(double);
+    if (lds > (size_t)150 * 1024) return fail(h, RSREC_ERR_ARG, "terminator: lld = %d too deep for the LDS staging", lld);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_terminator), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    k_terminator<<<dim3((BLK + T - 1) / T, n), T, lds, h->stream>>>(lld, d_ab, d_bs, d_ainf, d_binf);
+    HIPCK(h, hipGetLastError());
+    return RSREC_OK;
+}
+
+}  // namespace
+
+// recursion%get_terminf (recursion.f90:2092-2135) for `nsites` sites, host arrays in and out.
+extern "C" int rsrec_terminator(rsrec_t* h, int nsites, int lld, const double* a_b, const double* b_sqrt, double* a_inf, double* b_inf,
+                                double* a_inf0, double* b_inf0) {
+    if (!h) return RSREC_ERR_ARG;
+    if (nsites < 0 || lld < 2 || (nsites > 0 && (!a_b || !b_sqrt || !a_inf || !b_inf))) return fail(h, RSREC_ERR_ARG, "rsrec_terminator: bad argument");
+    if (nsites == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t cbytes = (size_t)nsites * lld * BLK * sizeof(double2), tbytes = (size_t)nsites * BLK * sizeof(double);
+    HIPCK(h, h->d_green_in.reserve(2 * cbytes));
+    HIPCK(h, h->d_term.reserve(2 * tbytes + 2 * (size_t)nsites * sizeof(double)));
+    double2* d_ab = h->d_green_in.as<double2>();
+    double2* d_bs = d_ab + (size_t)nsites * lld * BLK;
+    double* d_ai = h->d_term.as<double>();
+    double* d_bi = d_ai + (size_t)nsites * BLK;
+    double* d_a0 = d_bi + (size_t)nsites * BLK;
+    XFER(xfer_h2d(h, d_ab, a_b, cbytes));
+    XFER(xfer_h2d(h, d_bs, b_sqrt, cbytes));
+    reset_timing(h);
+    hipEvent_t e0 = next_event(h);
+    int rc = launch_terminator(h, nsites, lld, d_ab, d_bs, d_ai, d_bi);
+    if (rc) return rc;
+    k_terminator_means<<<(nsites + 63) / 64, 64, 0, h->stream>>>(d_ai, d_bi, d_a0, d_a0 + nsites, nsites);
+    hipEvent_t e1 = next_event(h);
+    XFER(xfer_d2h(h, a_inf, d_ai, tbytes));
+    XFER(xfer_d2h(h, b_inf, d_bi, tbytes));
+    if (a_inf0) XFER(xfer_d2h(h, a_inf0, d_a0, (size_t)nsites * sizeof(double)));
+    if (b_inf0) XFER(xfer_d2h(h, b_inf0, d_a0 + nsites, (size_t)nsites * sizeof(double)));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = h->t_hop_ms = ev_ms(e0, e1);
+    return RSREC_OK;
+}
+
+// The whole LDOS stage for the sites of the last rsrec_block_lanczos call, from the coefficients it left on the device:
+// zsqr (recursion.f90:1980) -> get_terminf (:2092) -> bgreen (green.f90:1191) -> the reduction of calculate_fermi (bands.f90:258-268).
+// Only the densities of states leave the GPU (18 doubles per site and energy instead of 648).
+extern "C" int rsrec_block_ldos(rsrec_t* h, int nen, const double* ene, double eta_re, double eta_im, int sym_term, int site_offset, int nsites_total,
+                                double* dtot, double* dosia, double* dosial, double* a_inf_out, double* b_inf_out) {
+    if (!h) return RSREC_ERR_ARG;
+    if (nen < 1 || !ene || !dtot || !dosia || !dosial || site_offset < 0) return fail(h, RSREC_ERR_ARG, "rsrec_block_ldos: bad argument");
+    if (h->res_kind != 1) return fail(h, RSREC_ERR_ARG, "rsrec_block_ldos: no block-Lanczos coefficients resident (call rsrec_block_lanczos first)");
+    const int n = h->res_n, lld = h->res_lld;
+    if (site_offset + n > nsites_total) return fail(h, RSREC_ERR_ARG, "rsrec_block_ldos: sites %d..%d outside 1..%d", site_offset + 1, site_offset + n, nsites_total);
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t cel = (size_t)n * lld * BLK;
+    HIPCK(h, h->d_bsqrt.reserve(cel * sizeof(double2)));
+    HIPCK(h, h->d_term.reserve(2 * (size_t)n * BLK * sizeof(double) + 2 * (size_t)n * sizeof(double)));
+    HIPCK(h, h->d_gim.reserve((size_t)n * nen * NB * sizeof(double) + (size_t)nen * sizeof(double)));
+    const size_t img = (size_t)nen * ((size_t)nsites_total * (NB + 1) + 1);          // dosial + dosia + dtot
+    const bool dev = is_device_ptr(dtot) && is_device_ptr(dosia) && is_device_ptr(dosial);
+    if (!dev) HIPCK(h, h->d_ldos.reserve(img * sizeof(double)));
+    HIPCK(h, h->d_status.reserve(64));
+    HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
+    double* d_gim = h->d_gim.as<double>();
+    double* d_ene = d_gim + (size_t)n * nen * NB;
+    XFER(xfer_h2d(h, d_ene, ene, (size_t)nen * sizeof(double)));
+    reset_timing(h);
+    hipEvent_t e0 = next_event(h);
+    const double2* dA = h->d_coefA.as<double2>();
+    double2* dBs = h->d_bsqrt.as<double2>();
+    // b2_b of the recursion stays B^2 (the caller may still fetch it); the stage works on its own square root
+    HIPCK(h, hipMemcpyAsync(dBs, h->d_coefB.p, cel * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    k_zsqr<<<n * lld, 256, 0, h->stream>>>(dBs, h->d_status.as<int>());
+    double* d_ai = h->d_term.as<double>();
+    double* d_bi = d_ai + (size_t)n * BLK;
+    int rc = launch_terminator(h, n, lld, dA, dBs, d_ai, d_bi);
+    if (rc) return rc;
+    hipEvent_t k0 = next_event(h);
+    {
+        const dim3 grid((nen + GREEN_WAVES - 1) / GREEN_WAVES, n);
+        k_block_green<true><<<grid, GREEN_WAVES * 64, 0, h->stream>>>(lld, nen, d_ene, eta_re, eta_im, sym_term, d_ai, d_bi, dA, dBs, nullptr, d_gim);
+    }
+    hipEvent_t k1 = next_event(h);
+    double* o_dosial = dev ? dosial : h->d_ldos.as<double>();
+    double* o_dosia = dev ? dosia : o_dosial + (size_t)nsites_total * NB * nen;
+    double* o_dtot = dev ? dtot : o_dosia + (size_t)nsites_total * nen;
+    k_ldos_finish<<<(nen + 63) / 64, 64, 0, h->stream>>>(d_gim, n, nen, site_offset, nsites_total, o_dosial, o_dosia, o_dtot);
+    HIPCK(h, hipGetLastError());
+    hipEvent_t e1 = next_event(h);
+    if (!dev) {
+        XFER(xfer_d2h(h, dosial, o_dosial, (size_t)nsites_total * NB * nen * sizeof(double)));
+        XFER(xfer_d2h(h, dosia, o_dosia, (size_t)nsites_total * nen * sizeof(double)));
+        XFER(xfer_d2h(h, dtot, o_dtot, (size_t)nen * sizeof(double)));
+    }
+    if (a_inf_out) XFER(xfer_d2h(h, a_inf_out, d_ai, (size_t)n * BLK * sizeof(double)));
+    if (b_inf_out) XFER(xfer_d2h(h, b_inf_out, d_bi, (size_t)n * BLK * sizeof(double)));
+    int status = 0;
+    XFER(xfer_d2h(h, &status, h->d_status.p, 4));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(e0, e1);
+    h->t_hop_ms = ev_ms(k0, k1);                      // the Green kernel alone
+    h->t_rest_ms = h->t_total_ms - h->t_hop_ms;       // zsqr + terminator + reduction
+    if (status & 1) return fail(h, RSREC_ERR_EIG, "Diagonalization error (18x18 Jacobi did not converge)");
     return RSREC_OK;
 }
 

@@ -41,6 +41,45 @@ class Green:
                                             int(self.sym_term), _ptr(a_inf), _ptr(b_inf), _ptr(a_b), _ptr(b_s), _ptr(g0)))
         return g0
 
+    def terminator(self, nsites=None):
+        """recursion%get_terminf (recursion.f90:2092) on the GPU for the coefficients held by the recursion object (b2_b after zsqr):
+        returns a_inf, b_inf (18,18,n) and the mean diagonals a_inf0, b_inf0 (n)."""
+        rec = self.recursion
+        n = rec.a_b.shape[3] if nsites is None else nsites
+        lld = rec.a_b.shape[2]
+        a_b = np.asfortranarray(rec.a_b[:, :, :, :n])
+        b_s = np.asfortranarray(rec.b2_b[:, :, :, :n])
+        a_inf = np.zeros((18, 18, n), np.float64, order="F")
+        b_inf = np.zeros_like(a_inf)
+        a0, b0 = np.zeros(n), np.zeros(n)
+        rec._check(rec._L.rsrec_terminator(rec._h, n, lld, _ptr(a_b), _ptr(b_s), _ptr(a_inf), _ptr(b_inf), _ptr(a0), _ptr(b0)))
+        return a_inf, b_inf, a0, b0
+
+    def block_ldos(self, eta=0.0 + 0.0j, site_offset=0, nsites_total=None, out=None):
+        """The LDOS stage for the sites of the last ``recur_b`` call, entirely on the device from the coefficients that call left
+        there: zsqr -> get_terminf -> bgreen -> the reduction of bands%calculate_fermi (bands.f90:258-268).  Returns a dict with the
+        zero-padded images ``dtot(nen)``, ``dosia(nsites_total, nen)``, ``dosial(nsites_total, 18, nen)`` and the terminators used.
+        ``out`` = (dtot, dosia, dosial) raw DEVICE addresses (e.g. ``tensor.data_ptr()``): the images are written there in place."""
+        import ctypes as C
+        rec = self.recursion
+        start, end = rec._my_sites()[:2]
+        n = end - start + 1
+        ntot = n + site_offset if nsites_total is None else nsites_total
+        nen = len(self.ene)
+        a_inf = np.zeros((18, 18, n), np.float64, order="F")
+        b_inf = np.zeros_like(a_inf)
+        if out is None:
+            dtot = np.zeros(nen)
+            dosia = np.zeros((ntot, nen), order="F")
+            dosial = np.zeros((ntot, 18, nen), order="F")
+            ptrs = (_ptr(dtot), _ptr(dosia), _ptr(dosial))
+        else:
+            dtot = dosia = dosial = None
+            ptrs = tuple(C.c_void_p(int(p)) for p in out)
+        rec._check(rec._L.rsrec_block_ldos(rec._h, nen, _ptr(self.ene), float(np.real(eta)), float(np.imag(eta)), int(self.sym_term),
+                                           int(site_offset), int(ntot), ptrs[0], ptrs[1], ptrs[2], _ptr(a_inf), _ptr(b_inf)))
+        return dict(dtot=dtot, dosia=dosia, dosial=dosial, a_inf=a_inf, b_inf=b_inf)
+
     def chebyshev_green(self, nsites=None):
         """green%chebyshev_green (green.f90:1030-1108): g0 from the Chebyshev moments ``recursion.mu_n``."""
         rec = self.recursion
