@@ -307,6 +307,7 @@ def main():
         if world > 1:
             # the path's one exchange, on the device: the library writes this rank's part of the image straight into the tensor
             # the collective reduces (no host round trip); gloo rehearsal reduces a host copy
+            torch.cuda.synchronize()          # the previous collective (torch's stream) has released the image
             if args.recur == "block":
                 rec.pack_diag(start - 1, nsites_total, img[0].data_ptr(), img[1].data_ptr())
             else:

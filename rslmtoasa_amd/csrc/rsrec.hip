@@ -12,6 +12,8 @@
 //  * work vectors (psi, pmn, ...) never leave HBM; only the 18x18 coefficients come back to the host;
 //  * reductions are two-stage and fixed-order (no float atomics) so results are run-to-run reproducible.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1058,11 +1060,22 @@ extern "C" int rsrec_block_lanczos(rsrec_t* h, int nsites, const int32_t* seed_a
 
 namespace {
 
-// true if p is device memory of this process (torch / hipMalloc allocations): outputs may then stay on the GPU
+// true if p is device memory of this process (torch / hipMalloc allocations): outputs may then stay on the GPU.
+// A Python process that imports torch holds TWO HIP runtimes (torch bundles its own libamdhip64; this library links the system one)
+// on top of ONE shared ROCr/HSA runtime and one GPU address space: a tensor's address is valid in our kernels, but our HIP runtime
+// has never heard of it.  So the question is put to ROCr (hsa_amd_pointer_info), which knows every allocation of the process.
 bool is_device_ptr(const void* p) {
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable host memory
-    return at.type == hipMemoryTypeDevice;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    hsa_amd_pointer_info_t info;
+    memset(&info, 0, sizeof info);
+    info.size = sizeof info;
+    if (hsa_amd_pointer_info(const_cast<void*>(p), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
+    if (info.type != HSA_EXT_POINTER_TYPE_HSA) return false;                          // unknown = plain pageable host memory
+    hsa_device_type_t dt = HSA_DEVICE_TYPE_CPU;
+    if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &dt) != HSA_STATUS_SUCCESS) return false;
+    return dt == HSA_DEVICE_TYPE_GPU;
 }
 
 // a(ll, l, site) = Re a_b(l, l, ll, site), b2 likewise (recursion.f90:1850-1851), written into zero-padded images over all sites

@@ -58,10 +58,12 @@ def test_resident_ldos_pipeline(name):
     assert np.abs(r["a_inf"] - z["a_inf"]).max() <= 1e-9 * np.abs(z["a_inf"]).max()      # continuous in the coefficients
     assert np.abs(r["b_inf"] - z["b_inf"]).max() <= 1e-9 * np.abs(z["b_inf"]).max()
     dtot, dosia, dosial = ldos_from_g0(z["g0"])
-    scale = np.abs(dosial).max(axis=(0, 1))                                             # per energy
-    assert (np.abs(r["dosial"] - dosial).max(axis=(0, 1)) <= 1e-9 * scale).all()
-    assert (np.abs(r["dosia"] - dosia).max(axis=0) <= 1e-9 * scale).all()
-    assert (np.abs(r["dtot"] - dtot) <= 1e-9 * n * scale).all()
+    # scale: the largest LDOS of the mesh.  (Outside the band Im g0 is rounding noise of either code, 1e-18 with eta = 0: a
+    # per-energy relative bound has no meaning there; inside the band the two agree to 1e-13.)
+    scale = np.abs(dosial).max()
+    assert np.abs(r["dosial"] - dosial).max() <= 1e-10 * scale
+    assert np.abs(r["dosia"] - dosia).max() <= 1e-10 * scale
+    assert np.abs(r["dtot"] - dtot).max() <= 1e-10 * n * scale
     # b2_b of the recursion is still B^2 (the stage takes its own square root): the host path gives the same numbers
     rec.zsqr()
     g0 = gr.block_green(r["a_inf"], r["b_inf"], nsites=n)
@@ -71,32 +73,70 @@ def test_resident_ldos_pipeline(name):
     rec.close()
 
 
-def test_ldos_images_are_zero_padded_and_device_outputs_match():
-    """The images the ranks all-reduce (bands.f90:271-274): this rank's sites at their global positions, zeros elsewhere; and
-    the same numbers when the outputs are device buffers (the tensors a collective would reduce)."""
-    import torch
+def test_ldos_images_are_zero_padded():
+    """The images the ranks all-reduce (bands.f90:271-274): this rank's sites at their global positions, zeros elsewhere."""
     name = "fccCu001_block_hoh"                                                          # two sites
     z = load_green(name)
     g = load_golden(name)
     rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
     rec.recur_b()
     gr = Green(rec, z["ene"])
-    n, nen, ntot, off = 2, len(z["ene"]), 5, 2
+    n, ntot, off = 2, 5, 2
     host = gr.block_ldos(site_offset=off, nsites_total=ntot)
     local = gr.block_ldos()
     assert np.array_equal(host["dosial"][off:off + n], local["dosial"]) and np.array_equal(host["dosia"][off:off + n], local["dosia"])
     assert np.array_equal(host["dtot"], local["dtot"])
     mask = np.ones(ntot, bool); mask[off:off + n] = False
     assert np.all(host["dosial"][mask] == 0) and np.all(host["dosia"][mask] == 0)
-    t_tot = torch.full((nen,), -1.0, dtype=torch.float64, device="cuda")
-    t_ia = torch.full((nen, ntot), -1.0, dtype=torch.float64, device="cuda")              # Fortran (ntot, nen)
-    t_ial = torch.full((nen, 18, ntot), -1.0, dtype=torch.float64, device="cuda")         # Fortran (ntot, 18, nen)
-    gr.block_ldos(site_offset=off, nsites_total=ntot, out=(t_tot.data_ptr(), t_ia.data_ptr(), t_ial.data_ptr()))
-    torch.cuda.synchronize()
-    assert np.array_equal(t_tot.cpu().numpy(), host["dtot"])
-    assert np.array_equal(t_ia.cpu().numpy().T, host["dosia"])
-    assert np.array_equal(t_ial.cpu().numpy().transpose(2, 1, 0), host["dosial"])
     rec.close()
+
+
+DEVICE_OUTPUT_SCRIPT = r"""
+import sys, numpy as np, torch
+torch.cuda.init(); torch.cuda.set_device(0)          # torch's HIP runtime first, as in bench.py
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import load_golden, objects_from, problem_dict
+from test_gpu_green import load_green
+from rslmtoasa_amd.green import Green
+from rslmtoasa_amd.recursion import Recursion
+name = "fccCu001_block_hoh"
+z, g = load_green(name), load_golden(name)
+rec = Recursion(*objects_from(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"]), device=0)
+rec.recur_b()
+gr = Green(rec, z["ene"])
+n, nen, ntot, off = 2, len(z["ene"]), 5, 2
+host = gr.block_ldos(site_offset=off, nsites_total=ntot)
+t_tot = torch.full((nen,), -1.0, dtype=torch.float64, device="cuda")
+t_ia = torch.full((nen, ntot), -1.0, dtype=torch.float64, device="cuda")              # Fortran (ntot, nen)
+t_ial = torch.full((nen, 18, ntot), -1.0, dtype=torch.float64, device="cuda")         # Fortran (ntot, 18, nen)
+torch.cuda.synchronize()
+gr.block_ldos(site_offset=off, nsites_total=ntot, out=(t_tot.data_ptr(), t_ia.data_ptr(), t_ial.data_ptr()))
+assert np.array_equal(t_tot.cpu().numpy(), host["dtot"])
+assert np.array_equal(t_ia.cpu().numpy().T, host["dosia"])
+assert np.array_equal(t_ial.cpu().numpy().transpose(2, 1, 0), host["dosial"])
+# the packed diagonal coefficients, same contract
+a_img = torch.full((ntot, 18, g["lld"]), -1.0, dtype=torch.float64, device="cuda")
+b_img = torch.full((ntot, 18, g["lld"]), -1.0, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+rec.pack_diag(off, ntot, a_img.data_ptr(), b_img.data_ptr())
+a = a_img.cpu().numpy()
+assert np.array_equal(a[off:off + n], rec.a[:g["lld"], :, :n, 0].transpose(2, 1, 0)) and np.all(a[:off] == 0) and np.all(a[off + n:] == 0)
+ah = np.zeros((g["lld"], 18, ntot), order="F"); bh = np.zeros_like(ah)
+rec.pack_diag(off, ntot, ah, bh)
+assert np.array_equal(ah.transpose(2, 1, 0), a) and np.array_equal(bh.transpose(2, 1, 0), b_img.cpu().numpy())
+rec.close()
+print("DEVICE_OUTPUT_OK")
+"""
+
+
+def test_device_outputs_match_host_outputs():
+    """Outputs handed over as DEVICE buffers (the tensors a collective would reduce) receive the same numbers as host arrays.
+    Own process: torch's HIP runtime has to be initialised before librsrec's (as in bench.py); the other tests of this session
+    have already started librsrec's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", DEVICE_OUTPUT_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DEVICE_OUTPUT_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 def test_ldos_positive_on_full_mesh():
