@@ -153,6 +153,31 @@ int rsrec_chebyshev(rsrec_t *h, int nsites, const int32_t *seed_atoms, int lld, 
 int rsrec_chebyshev_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
                            int lld, double a, double b, double *mu_n);
 
+/* Stochastic Kubo-Bastin double moments.  Replaces compute_moments_stochastic (recursion.f90:979-1234) together with the
+ * whole-vector products it is built from: ham_vec_matmul (:913), ham_hoh_vec_matmul (:785), velo_vec_matmul (:587),
+ * velo_hoh_vec_matmul (:656):
+ *   mu(:,:,n,m,i) = sum_k [ T_{m-1}(H~) r_i ]_k^H  [ v_a T_{n-1}(H~) v_b r_i ]_k ,   H~ = (H - b)/a ,  n, m = 1..cond_ll
+ * with H the operator set by rsrec_set_hamiltonian (hoh included), T the Chebyshev polynomials (three-term recurrence on whole
+ * vectors) and the sum running over every atom k of the lattice.
+ *   nvec vectors; vector i starts from psiref(l,l,seed(k,i)) = coef(k,i), k = 1..nseed (seed = 0: entry unused):
+ *     cond_calctype = 'per_type'   : one seed, the type's atom lattice%atlist(i), coefficient 1            (:1093-1102)
+ *     cond_calctype = 'random_vec' : nseed = kk, coefficient exp(2 pi i rng_k) / sqrt(kk) from the caller's generator (:1103-1114)
+ *   seed_atoms : int32 (nseed, nvec);  seed_coef : complex (nseed, nvec)
+ *   a, b : scale and shift as in rsrec_chebyshev (:1023-1024)
+ *   v_a, v_b   : complex (18,18,nslots,ntype), hamiltonian%v_a / %v_b as setup_kubo_operators (:242) left them
+ *   vo_a, vo_b : complex (18,18,nslots,ntype), hamiltonian%vo_a / %vo_b (hoh only, else NULL)
+ *   mu_nm : complex (18,18,cond_ll,cond_ll,nvec) out = recursion%mu_nm_stochastic
+ * The velocity operators act on the bulk (per-type) atoms only, as in the reference (:591, "not yet implemented" for the
+ * per-atom region): rows of v psi on the first nmax atoms are zero. */
+int rsrec_kubo_moments(rsrec_t *h, int nvec, int nseed, const int32_t *seed_atoms, const double *seed_coef, int cond_ll, double a, double b,
+                       const double *v_a, const double *vo_a, const double *v_b, const double *vo_b, double *mu_nm);
+
+/* One whole-vector product on caller arrays psi(18,18,kk) (complex, the reference's layout):
+ *   vel = 0 : psi_out = (H psi_in - b psi_in)/a      ham_vec_matmul (:913) / ham_hoh_vec_matmul (:785); v_op, vo_op ignored
+ *   vel = 1 : psi_out = V psi_in                      velo_vec_matmul (:587, 'n') / velo_hoh_vec_matmul (:656) with v_op (and vo_op with hoh)
+ * (The type-bound procedures of those names can be overridden with this; chebyshev_orbital_mod :2834 then runs its products on the GPU.) */
+int rsrec_apply_operator(rsrec_t *h, int vel, const double *v_op, const double *vo_op, const double *psi_in, double *psi_out, double a, double b);
+
 /* Scalar Haydock recursion, one chain per (site, orbital).  Replaces recur (recursion.f90:3485-3532),
  * crecal (:3423-3478), hop (:3310-3416).
  *   a, b2 : real (llmax,18,nsites) out (the (:,:,:,1) plane of the reference's a/b2); rows > lld are zeroed. */

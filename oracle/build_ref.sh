@@ -39,7 +39,7 @@ ar rcs "$OUT/librslmto_ref.a" $OBJS
 LDFLAGS="-fopenmp -L$MKLDIR -lmkl_rt -Wl,-rpath,$MKLDIR"
 (cd "$OUT/obj" && "$FC" $FFLAGS -c "$SRC/main.f90" -o "$OUT/obj/main.o")
 "$FC" "$OUT/obj/main.o" "$OUT/librslmto_ref.a" $LDFLAGS -o "$OUT/rslmto_ref.x"
-for drv in dump_fixture ref_kernel; do
+for drv in dump_fixture ref_kernel dump_kubo; do
   if [ -f "$HERE/$drv.f90" ]; then
     (cd "$OUT/obj" && "$FC" $FFLAGS -c "$HERE/$drv.f90" -o "$OUT/obj/$drv.o")
     "$FC" "$OUT/obj/$drv.o" "$OUT/librslmto_ref.a" $LDFLAGS -o "$OUT/$drv.x"

@@ -232,6 +232,69 @@ SUPERCELLS = {
 }
 
 
+KUBO_CASES = {
+    # tests/postproc/cases.json "Example_exchange_conductivity_fccPt" / "_hoh" (cond_type = 'spin', per_type), cell and moment count
+    # reduced so that the fixture stays small: n = 8^3 fcc cell, cond_ll = 10 (the case runs 20^3, cond_ll = 50)
+    "fccPt_kubo": ("tests/postproc/cases/conductivity/fccPt", {"lattice": {"n1": 8, "n2": 8, "n3": 8}, "control": {"cond_ll": 10, "lld": 10}, "hamiltonian": {"hoh": ".false."}}),
+    "fccPt_kubo_hoh": ("tests/postproc/cases/conductivity/fccPt", {"lattice": {"n1": 8, "n2": 8, "n3": 8}, "control": {"cond_ll": 10, "lld": 10}, "hamiltonian": {"hoh": ".true."}}),
+}
+
+
+def run_kubo_case(name):
+    """<name>.npz: inputs and output of recursion%compute_moments_stochastic (recursion.f90:979) from the compiled reference
+    (oracle/_ref/dump_kubo.x = the reference modules + oracle/dump_kubo.f90, which replays calculation.f90:960-1052)."""
+    import struct
+    case_dir, patch = KUBO_CASES[name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_kubo_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        p = os.path.join(scratch, "input.nml")
+        txt = open(p).read()
+        # the case file holds TWO &hamiltonian groups; a namelist read takes the first one, so the second (hoh only) is dropped and
+        # the patch goes into the first
+        head, sep, tail = txt.rpartition("&hamiltonian")
+        if "&hamiltonian" in head:
+            txt = head + tail[tail.index("/") + 1:]
+        # the case file still carries two keys the reference's namelists no longer declare (js_alpha, cond_type): the read of the
+        # group stops there with an error the reference only logs, silently dropping every later key.  They are removed here so
+        # that the whole group (hoh, cond_calctype) is read.
+        txt = "\n".join(l for l in txt.splitlines() if not re.match(r"\s*(js_alpha|cond_type)\s*=", l)) + "\n"
+        txt = patch_namelist(txt, patch)
+        open(p, "w").write(txt)
+        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_kubo.x")
+        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "kubo.bin")):
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_kubo failed for " + name)
+        with open(os.path.join(scratch, "kubo.bin"), "rb") as f:
+            magic, version = struct.unpack("<ii", f.read(8))
+            assert magic == 0x4b55424f
+            kk, nncols, nmax, ntype, cond_ll, nsp, hoh, nslots, nvec = struct.unpack("<9i", f.read(36))
+            a, b = struct.unpack("<2d", f.read(16))
+            rd = fio._rd
+            d = dict(kk=kk, nmax=nmax, ntype=ntype, cond_ll=cond_ll, nsp=nsp, hoh=hoh, nslots=nslots, acheb=a, bcheb=b)
+            d["iz"] = rd(f, np.int32, (kk,)); d["nn"] = rd(f, np.int32, (kk, nncols)); d["atlist"] = rd(f, np.int32, (ntype,))
+            for k, shape in (("ee", (18, 18, nslots, ntype)), ("lsham", (18, 18, ntype)), ("eeo", (18, 18, nslots, ntype)), ("enim", (18, 18, ntype)),
+                             ("v_a", (18, 18, nslots, ntype)), ("v_b", (18, 18, nslots, ntype)), ("vo_a", (18, 18, nslots, ntype)), ("vo_b", (18, 18, nslots, ntype))):
+                d[k] = rd(f, np.complex128, shape)
+            d["mu_nm"] = rd(f, np.complex128, (18, 18, cond_ll, cond_ll, nvec))
+            assert f.read(1) == b""
+        if not hoh:
+            for k in ("eeo", "enim", "vo_a", "vo_b"):
+                d.pop(k)
+        d["source_case"] = np.array(case_dir); d["namelist_patch"] = np.array(repr(patch))
+        path = os.path.join(GOLD, name + ".npz")
+        np.savez_compressed(path, **d)
+        wall = [l for l in r.stdout.splitlines() if "wall time" in l]
+        print("%-24s kk=%d nslots=%d cond_ll=%d hoh=%d |mu|max=%.3e -> %.1f KB  (%s)" % (name, kk, nslots, cond_ll, hoh, np.abs(d["mu_nm"]).max(),
+                                                                                   os.path.getsize(path) / 1024, wall[-1].strip() if wall else ""))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def spread_case(name, threads=(1, 2, 8)):
     """<name>_spread.npz: the compiled reference's OWN run-to-run spread on a supercell case -- the same ref_kernel.x run at
     several OpenMP thread counts (its reductions are `omp reduction` sums, recursion.f90:1638-1645: the summation order depends
@@ -254,9 +317,12 @@ def spread_case(name, threads=(1, 2, 8)):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)])
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES)
+                            + ["sc_4x4x8_block_spread", "sc_4x4x8_block_hoh_spread"])
     for n in want:
-        if n.endswith("_spread"):
+        if n in KUBO_CASES:
+            run_kubo_case(n)
+        elif n.endswith("_spread"):
             spread_case(n[:-len("_spread")])
         elif n.endswith("_green"):
             run_green_case(n[:-len("_green")])

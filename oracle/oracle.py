@@ -105,6 +105,21 @@ class Oracle:
                                  mu.ctypes.data_as(C.c_void_p))
         return mu, rc
 
+    def kubo_moments(self, seeds, coefs, cond_ll, a, b, v_a, v_b, vo_a=None, vo_b=None):
+        """compute_moments_stochastic (recursion.f90:979): seeds (nvec, nseed) int, coefs (nvec, nseed) complex -> mu (18,18,cond_ll,cond_ll,nvec)."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        coefs = np.ascontiguousarray(coefs, dtype=np.complex128)
+        nvec, ns = seeds.shape
+        mu = np.zeros((18, 18, cond_ll, cond_ll, nvec), np.complex128, order="F")
+        keep = [None if v is None else _f(v, np.complex128) for v in (v_a, vo_a, v_b, vo_b)]
+        p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+        L = lib()
+        L.orc_kubo_moments.restype = C.c_int
+        L.orc_kubo_moments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 5
+        rc = L.orc_kubo_moments(C.byref(self.P), nvec, ns, p(seeds), p(coefs), int(cond_ll), float(a), float(b), p(keep[0]), p(keep[1]), p(keep[2]), p(keep[3]), p(mu))
+        assert rc == 0
+        return mu
+
     def scalar_lanczos(self, seeds, lld, llmax=None):
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         n = len(seeds)

@@ -27,6 +27,8 @@ _SIGNATURES = {
     "rsrec_pack_diag": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_terminator": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "rsrec_block_ldos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "rsrec_kubo_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 5),
+    "rsrec_apply_operator": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
     "rsrec_zsqr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rsrec_chebyshev_green": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "rsrec_block_green": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 5),

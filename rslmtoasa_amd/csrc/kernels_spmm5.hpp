@@ -126,6 +126,33 @@ struct Spmm5Operator {
                     if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
                 }
             }
+        return upload(host, meta);
+    }
+    // General table: blk[(set * ntau + tau) * (nslots + 1) + s] = column-major interleaved 18x18 complex block of operator class tau,
+    // fragment slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes
+    // nothing and is not scheduled).  Used for operators other than H itself: the Kubo velocity operators (velo_vec_matmul,
+    // recursion.f90:587) and their hoh combinations.
+    const char* build_custom(int nslots_lat, int ntau_, int nset, const std::vector<const double*>& blk) {
+        if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
+        ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0;
+        const int nfs = nslots + 1;
+        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT;
+        std::vector<double> host(per_set * nset, 0.0);
+        std::vector<int> meta((size_t)nset * ntau * META, 0);
+        for (int set = 0; set < nset; ++set)
+            for (int tau = 0; tau < ntau; ++tau) {
+                int* M = meta.data() + ((size_t)set * ntau + tau) * META;
+                for (int s = 0; s < nfs; ++s) {
+                    const double* src = blk[((size_t)set * ntau + tau) * nfs + s];
+                    if (!src) continue;
+                    swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
+                    M[1 + M[0]] = s; M[0]++;
+                    if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
+                }
+            }
+        return upload(host, meta);
+    }
+    const char* upload(const std::vector<double>& host, const std::vector<int>& meta) {
         const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
         if (need > frag_bytes) {
             if (d_frag) (void)hipFree(d_frag);

@@ -33,6 +33,8 @@
 #include "kernels_uscheme.hpp"
 #include "kernels_green.hpp"
 #include "kernels_ldos.hpp"
+#include "kernels_kubo.hpp"
+#include <dlfcn.h>
 
 using namespace rsrec;
 
@@ -81,6 +83,9 @@ struct rsrec_handle {
     int s4_built_split = 0;
     Spmm5Operator s5_op;
     int s5_built = 0;
+    std::vector<double> host_ee;       // ee as last set (the hoh velocity product needs h restricted to the bulk atoms)
+    Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
+    void* rocblas_lib = nullptr; void* rocblas_handle = nullptr;
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
     DevBuf d_bsqrt, d_term, d_gim, d_ldos;   // LDOS stage on resident coefficients: sqrt(B^2), terminators, Im g0_jj, output images
@@ -116,6 +121,8 @@ struct rsrec_handle {
 };
 
 namespace {
+
+int (*g_rocblas_destroy)(void*) = nullptr;     // set when rocBLAS is bound (Kubo path)
 
 int fail(rsrec_t* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -315,6 +322,8 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     h->mfma_op.release();
     h->s4_op.release();
     h->s5_op.release();
+    h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release();
+    if (h->rocblas_handle && g_rocblas_destroy) g_rocblas_destroy(h->rocblas_handle);
     if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -466,6 +475,7 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
     const size_t B = 2 * (size_t)BLK;   // doubles per block
     const int ntype = h->ntype, nmax = h->nmax;
     h->hslots = nslots; h->hoh = hoh ? 1 : 0; h->nsp = nsp;
+    h->host_ee.assign(ee, ee + 2 * (size_t)BLK * nslots * h->ntype);
     // stencil with the on-site spin-orbit block folded into slot 0 (locham = ee(:,:,1,ih) + lsham(:,:,ih), recursion.f90:1608)
     std::vector<double> st(ee, ee + B * nslots * ntype);
     if (!hoh)
@@ -1569,6 +1579,296 @@ extern "C" int rsrec_chebyshev_seeded(rsrec_t* h, int nchains, int nseed, const 
 
 extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double a, double b, double* mu_n) {
     return rsrec_chebyshev_seeded(h, nsites, 1, seed_atoms, nullptr, lld, a, b, mu_n);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stochastic Kubo double moments
+namespace {
+
+// rocBLAS is bound at the first Kubo call only (dlopen): the recursion / LDOS paths do not depend on it.
+struct RocblasApi {
+    int (*create)(void**) = nullptr;
+    int (*destroy)(void*) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*zgemm)(void*, int, int, int, int, int, const void*, const void*, int, const void*, int, const void*, void*, int) = nullptr;
+};
+RocblasApi g_rocblas;
+
+int rocblas_ready(rsrec_t* h) {
+    if (!h->rocblas_lib) {
+        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return fail(h, RSREC_ERR_DEVICE, "rocBLAS not found (needed for the moment GEMM of the Kubo path): %s", dlerror());
+        g_rocblas.create = reinterpret_cast<int (*)(void**)>(dlsym(lib, "rocblas_create_handle"));
+        g_rocblas.destroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "rocblas_destroy_handle"));
+        g_rocblas_destroy = g_rocblas.destroy;
+        g_rocblas.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(lib, "rocblas_set_stream"));
+        g_rocblas.zgemm = reinterpret_cast<decltype(g_rocblas.zgemm)>(dlsym(lib, "rocblas_zgemm"));
+        if (!g_rocblas.create || !g_rocblas.set_stream || !g_rocblas.zgemm) return fail(h, RSREC_ERR_DEVICE, "rocBLAS symbols missing");
+        h->rocblas_lib = lib;
+    }
+    if (!h->rocblas_handle) {
+        if (g_rocblas.create(&h->rocblas_handle) != 0) return fail(h, RSREC_ERR_DEVICE, "rocblas_create_handle failed");
+        if (g_rocblas.set_stream(h->rocblas_handle, h->stream) != 0) return fail(h, RSREC_ERR_DEVICE, "rocblas_set_stream failed");
+    }
+    return RSREC_OK;
+}
+
+// Operator tables of a velocity-type operator (recursion.f90:587-784): which = 0 -> kubo_op[0] (v_a), 1 -> kubo_op[1] (v_b).
+//   set 0: V itself -- per-type blocks v_op(:,:,slot,type) for the bulk atoms; the reference has no velocity operator for the
+//          per-atom (impurity) region yet (":591 NOT YET IMPLEMENTED"): those rows of V psi are zero, as there.
+//   set 1 (hoh): -vo_op(:,:,slot,type) for slots >= 2 and the identity in the extra slot, so that one pass over h psi with V psi as
+//          second input gives  V psi - sum_{slot >= 2} vo_slot (h psi)_nbr  (velo_hoh_vec_matmul :750-776; its on-site vo term is
+//          commented out in the reference, its e_nu / l.s terms are zero).
+int build_kubo_operator(rsrec_t* h, int which, const double* v, const double* vo) {
+    const int ntau = h->nmax + h->ntype, nfs = h->nslots + 1, nset = h->hoh ? 2 : 1;
+    const size_t B = 2 * (size_t)BLK;
+    std::vector<const double*> blk((size_t)nset * ntau * nfs, nullptr);
+    std::vector<double> neg((size_t)h->ntype * h->nslots * B, 0.0), ident(B, 0.0);
+    for (int d = 0; d < NB; ++d) ident[2 * (d + NB * d)] = 1.0;
+    for (int t = 0; t < h->ntype; ++t)
+        for (int s = 0; s < h->nslots; ++s) {
+            blk[((size_t)0 * ntau + h->nmax + t) * nfs + s] = v + B * (s + (size_t)h->hslots * t);
+            if (nset > 1 && s >= 1) {
+                double* d = neg.data() + B * (s + (size_t)h->nslots * t);
+                const double* src = vo + B * (s + (size_t)h->hslots * t);
+                for (size_t e = 0; e < B; ++e) d[e] = -src[e];
+                blk[((size_t)1 * ntau + h->nmax + t) * nfs + s] = d;
+            }
+        }
+    if (nset > 1)
+        for (int t = 0; t < h->ntype; ++t) blk[((size_t)1 * ntau + h->nmax + t) * nfs + h->nslots] = ident.data();
+    const char* msg = h->kubo_op[which].build_custom(h->nslots, ntau, nset, blk);
+    if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %s", msg);
+    return RSREC_OK;
+}
+
+// h restricted to the bulk atoms (psi1 of velo_hoh_vec_matmul :727-741 is only formed for k > nmax)
+int build_kubo_hbulk(rsrec_t* h) {
+    const int ntau = h->nmax + h->ntype, nfs = h->nslots + 1;
+    const size_t B = 2 * (size_t)BLK;
+    std::vector<const double*> blk((size_t)ntau * nfs, nullptr);
+    for (int t = 0; t < h->ntype; ++t)
+        for (int s = 0; s < h->nslots; ++s) blk[((size_t)h->nmax + t) * nfs + s] = h->host_ee.data() + B * (s + (size_t)h->hslots * t);
+    const char* msg = h->kubo_hbulk.build_custom(h->nslots, ntau, 1, blk);
+    if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %s", msg);
+    return RSREC_OK;
+}
+
+struct KuboCtx {
+    rsrec_t* h;
+    SpmmDims SD;
+    ChainView CV;
+    dim3 grid;
+    const int* iz;
+    double *hps, *p1, *p2;      // temporaries of the two-pass products
+};
+
+void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double* in, double* out, const double* in2) {
+    rsrec_t* h = K.h;
+    if (in2) k_spmm5<true><<<K.grid, S5_WG_GROUPS * 128, 0, h->stream>>>(K.SD, K.CV.order, K.CV.cum, h->d_nbr5.as<int>(), K.iz, op.frag_set(set), op.meta_set(set), in, out, in2);
+    else k_spmm5<false><<<K.grid, S5_WG_GROUPS * 128, 0, h->stream>>>(K.SD, K.CV.order, K.CV.cum, h->d_nbr5.as<int>(), K.iz, op.frag_set(set), op.meta_set(set), in, out);
+}
+// out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift)
+void kubo_apply_h(const KuboCtx& K, const double* in, double* out) {
+    if (!K.h->hoh) { kubo_spmm(K, K.h->s5_op, 0, in, out, nullptr); return; }
+    kubo_spmm(K, K.h->s5_op, 0, in, K.hps, nullptr);
+    kubo_spmm(K, K.h->s5_op, 1, K.hps, out, in);
+}
+// out = V in   (velo_vec_matmul :587 / velo_hoh_vec_matmul :656)
+void kubo_apply_v(const KuboCtx& K, const Spmm5Operator& vop, const double* in, double* out) {
+    if (!K.h->hoh) { kubo_spmm(K, vop, 0, in, out, nullptr); return; }
+    kubo_spmm(K, vop, 0, in, K.p2, nullptr);
+    kubo_spmm(K, K.h->nmax > 0 ? K.h->kubo_hbulk : K.h->s5_op, 0, in, K.p1, nullptr);
+    kubo_spmm(K, vop, 1, K.p1, out, K.p2);
+}
+
+}  // namespace
+
+// compute_moments_stochastic (recursion.f90:979-1234):  mu(:,:,n,m,i) = sum_k [T_{m-1}(H~) r_i]_k^H [v_a T_{n-1}(H~) v_b r_i]_k,
+// H~ = (H - b)/a.  The SpMMs are k_spmm5 over all atoms (blocks outside the reference's growing region are exact zeros); the
+// cond_ll x cond_ll moment contraction of a vector is one complex GEMM  L^H R  over the (atom, row) index (rocBLAS zgemm).
+extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t* seed_atoms, const double* seed_coef, int cond_ll, double a, double b,
+                                  const double* v_a, const double* vo_a, const double* v_b, const double* vo_b, double* mu_nm) {
+    int rc = check_ready(h, "rsrec_kubo_moments");
+    if (rc) return rc;
+    if (nvec < 0 || nseed < 1 || cond_ll < 1 || a == 0.0 || !v_a || !v_b || !mu_nm || (nvec > 0 && (!seed_atoms || !seed_coef)))
+        return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: bad argument");
+    if (h->hoh && (!vo_a || !vo_b)) return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: hoh requires vo_a and vo_b");
+    if (!h->s5_built) return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: lattice has too many neighbour slots for the SpMM kernel");
+    for (size_t q = 0; q < (size_t)nvec * nseed; ++q)
+        if (seed_atoms[q] < 0 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: seed atom %d outside 0..%d", seed_atoms[q], h->kk);
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nvec == 0) return RSREC_OK;
+    rc = rocblas_ready(h); if (rc) return rc;
+    rc = build_kubo_operator(h, 0, v_a, vo_a); if (rc) return rc;
+    rc = build_kubo_operator(h, 1, v_b, vo_b); if (rc) return rc;
+    if (h->hoh && h->nmax > 0) { rc = build_kubo_hbulk(h); if (rc) return rc; }
+    const int kk = h->kk;
+    const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
+    const size_t ld = (size_t)kk * NB;                       // rows of the moment matrices: (atom, orbital row)
+    const int nchunk = std::min(cond_ll, 64);                // right vectors per GEMM
+    // device memory: 11 work vectors, the left matrix (cond_ll vectors), one chunk of right vectors, one chunk of moments
+    const size_t need = 11 * velems * 8 + ((size_t)cond_ll + nchunk) * ld * NB * 16 + (size_t)cond_ll * NB * nchunk * NB * 16;
+    size_t free_b = 0, total_b = 0;
+    HIPCK(h, hipMemGetInfo(&free_b, &total_b));
+    size_t reusable = 0;
+    for (int v = 0; v < 6; ++v) reusable += h->d_vec[v].bytes;
+    if ((double)need > 0.9 * (double)(free_b + reusable))
+        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for cond_ll = %d on %d atoms, %.1f GB free", need * 1e-9, cond_ll, kk, free_b * 1e-9);
+    for (int v = 0; v < 6; ++v) h->d_vec[v].release();
+    DevBuf work, Lm, Rm, Mu;
+    auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Mu.release(); };
+    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)cond_ll * ld * NB * 16) != hipSuccess ||
+        Rm.reserve((size_t)nchunk * ld * NB * 16) != hipSuccess || Mu.reserve((size_t)cond_ll * NB * nchunk * NB * 16) != hipSuccess) {
+        cleanup();
+        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: out of device memory");
+    }
+    HIPCK(h, hipMemsetAsync(work.p, 0, 11 * velems * 8, h->stream));            // block kk of every vector stays the zero block
+    double* V[11];
+    for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * velems;
+    double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3], *t = V[4], *right = V[5];
+    HIPCK(h, h->d_seed.reserve((size_t)nseed * 4));
+    HIPCK(h, h->d_seedcoef.reserve((size_t)nseed * sizeof(double2)));
+    // region list: all atoms (every launch of this path runs over the whole lattice)
+    std::vector<int> all(kk);
+    for (int i = 0; i < kk; ++i) all[i] = i;
+    int ostride = kk;
+    double dummy1 = 0, dummy2 = 0;
+    rc = upload_regions(h, all.data(), 1, kk, 1, 1, false, true, ostride, dummy1, dummy2);
+    if (rc) { cleanup(); return rc; }
+    KuboCtx K;
+    K.h = h;
+    K.CV.order = h->cur_order; K.CV.cum = h->cur_cum; K.CV.obase = h->cur_cum + (size_t)h->cur_nrows * 1; K.CV.nlev = 1; K.CV.vstride = velems; K.CV.cpo = 1; K.CV.ostride = ostride;
+    K.SD = SpmmDims{kk, h->nslots, h->nmax, 1, 1, ostride, 0, velems, K.CV.obase, 1};
+    K.grid = s5_grid(h, dim3(256, 1), 0);
+    K.iz = h->d_iz.as<int>();
+    K.hps = V[6]; K.p1 = V[7]; K.p2 = V[8];
+    const int cgrid = (int)std::min<size_t>(4096, (nd + 255) / 256);
+    const int m_rows = cond_ll * NB;
+    std::vector<double> mu_chunk((size_t)m_rows * nchunk * NB * 2);
+    hipEvent_t e_begin = next_event(h);
+    for (int iv = 0; iv < nvec; ++iv) {
+        // r_i: psiref(l,l,seed(k)) = coef(k); seed atom 0 = unused entry
+        std::vector<int> s0; std::vector<double> c0;
+        for (int k = 0; k < nseed; ++k) {
+            const int at = seed_atoms[(size_t)iv * nseed + k];
+            if (at == 0) continue;
+            s0.push_back(at - 1); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k)]); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k) + 1]);
+        }
+        if (s0.empty()) { cleanup(); return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: vector %d has no seed", iv + 1); }
+        XFER(xfer_h2d(h, h->d_seed.p, s0.data(), s0.size() * 4));
+        XFER(xfer_h2d(h, h->d_seedcoef.p, c0.data(), c0.size() * 8));
+        HIPCK(h, hipMemsetAsync(psiref, 0, nd * 8, h->stream));
+        k_seed<LayoutCI><<<1, 64, 0, h->stream>>>(psiref, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), (int)s0.size());
+        // left vectors  T_{m-1}(H~) r  ->  columns of L (recursion.f90:1120-1142)
+        double *x0 = w0, *x1 = w1, *x2 = w2;
+        HIPCK(h, hipMemcpyAsync(x1, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
+        for (int m = 0; m < cond_ll; ++m) {
+            if (m == 1) {
+                std::swap(x0, x1);                                        // w0 = w1
+                kubo_apply_h(K, x0, t);
+                k_cheb_combine<true><<<cgrid, 256, 0, h->stream>>>(nd, t, x0, nullptr, x1, a, b);
+            } else if (m > 1) {
+                kubo_apply_h(K, x1, t);
+                k_cheb_combine<false><<<cgrid, 256, 0, h->stream>>>(nd, t, x1, x0, x2, a, b);
+                double* o = x0; x0 = x1; x1 = x2; x2 = o;                 // w0 = w1, w1 = w2
+            }
+            k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(x1), Lm.as<double2>(), ld, m * NB);
+        }
+        // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), contracted with all left vectors chunk by chunk
+        x0 = w0; x1 = w1; x2 = w2;
+        kubo_apply_v(K, h->kubo_op[1], psiref, x1);                       // v1 = v0 = v_b r
+        for (int n = 0; n < cond_ll; ++n) {
+            if (n == 1) {
+                std::swap(x0, x1);
+                kubo_apply_h(K, x0, t);
+                k_cheb_combine<true><<<cgrid, 256, 0, h->stream>>>(nd, t, x0, nullptr, x1, a, b);
+            } else if (n > 1) {
+                kubo_apply_h(K, x1, t);
+                k_cheb_combine<false><<<cgrid, 256, 0, h->stream>>>(nd, t, x1, x0, x2, a, b);
+                double* o = x0; x0 = x1; x1 = x2; x2 = o;
+            }
+            kubo_apply_v(K, h->kubo_op[0], x1, right);
+            const int nl = n % nchunk;
+            k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(right), Rm.as<double2>(), ld, nl * NB);
+            if (nl == nchunk - 1 || n == cond_ll - 1) {
+                const int ncols = (nl + 1) * NB;
+                const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
+                HIPCK(h, hipGetLastError());
+                // Mu[(m,c), (n,c')] = sum_{k,r} conj(L[(k,r),(m,c)]) R[(k,r),(n,c')]    (zgemm 'C','N'; rocblas_operation codes 113 / 111)
+                if (g_rocblas.zgemm(h->rocblas_handle, 113, 111, m_rows, ncols, (int)ld, one, Lm.p, (int)ld, Rm.p, (int)ld, zero, Mu.p, m_rows) != 0) {
+                    cleanup();
+                    return fail(h, RSREC_ERR_DEVICE, "rocblas_zgemm failed");
+                }
+                XFER(xfer_d2h(h, mu_chunk.data(), Mu.p, (size_t)m_rows * ncols * 16));
+                const int n0 = n - nl;
+                for (int q = 0; q <= nl; ++q)
+                    for (int cp = 0; cp < NB; ++cp)
+                        for (int m = 0; m < cond_ll; ++m)
+                            for (int c = 0; c < NB; ++c) {
+                                const size_t src = 2 * ((size_t)(m * NB + c) + (size_t)m_rows * (q * NB + cp));
+                                const size_t dst = 2 * ((size_t)c + NB * ((size_t)cp + NB * ((size_t)(n0 + q) + cond_ll * ((size_t)m + (size_t)cond_ll * iv))));
+                                mu_nm[dst] = mu_chunk[src]; mu_nm[dst + 1] = mu_chunk[src + 1];
+                            }
+            }
+        }
+    }
+    hipEvent_t e_end = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipGetLastError());
+    h->t_total_ms = ev_ms(e_begin, e_end);
+    h->n_hop_launch = (double)nvec * (3.0 * cond_ll - 1) * (h->hoh ? 2 : 1);
+    cleanup();
+    return RSREC_OK;
+}
+
+// ham_vec_matmul / ham_hoh_vec_matmul (recursion.f90:913 / :785): psi_out = (H psi_in - b psi_in) / a on whole vectors
+// psi(18,18,kk) in the reference's layout (host arrays); with vel = 1: velo_vec_matmul / velo_hoh_vec_matmul (:587 / :656) with
+// the operator blocks v_op (and vo_op with hoh), no scaling.
+extern "C" int rsrec_apply_operator(rsrec_t* h, int vel, const double* v_op, const double* vo_op, const double* psi_in, double* psi_out, double a, double b) {
+    int rc = check_ready(h, "rsrec_apply_operator");
+    if (rc) return rc;
+    if (!psi_in || !psi_out || (!vel && a == 0.0) || (vel && (!v_op || (h->hoh && !vo_op)))) return fail(h, RSREC_ERR_ARG, "rsrec_apply_operator: bad argument");
+    if (!h->s5_built) return fail(h, RSREC_ERR_ARG, "rsrec_apply_operator: lattice has too many neighbour slots for the SpMM kernel");
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    const int kk = h->kk;
+    const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
+    if (vel) { rc = build_kubo_operator(h, 0, v_op, vo_op); if (rc) return rc; if (h->hoh && h->nmax > 0) { rc = build_kubo_hbulk(h); if (rc) return rc; } }
+    for (int v = 0; v < 6; ++v) HIPCK(h, h->d_vec[v].reserve(velems * 8));
+    for (int v = 0; v < 6; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, velems * 8, h->stream));
+    std::vector<int> all(kk);
+    for (int i = 0; i < kk; ++i) all[i] = i;
+    int ostride = kk;
+    double dummy1 = 0, dummy2 = 0;
+    rc = upload_regions(h, all.data(), 1, kk, 1, 1, false, true, ostride, dummy1, dummy2);
+    if (rc) return rc;
+    KuboCtx K;
+    K.h = h;
+    K.CV.order = h->cur_order; K.CV.cum = h->cur_cum; K.CV.obase = h->cur_cum + (size_t)h->cur_nrows * 1; K.CV.nlev = 1; K.CV.vstride = velems; K.CV.cpo = 1; K.CV.ostride = ostride;
+    K.SD = SpmmDims{kk, h->nslots, h->nmax, 1, 1, ostride, 0, velems, K.CV.obase, 1};
+    K.grid = s5_grid(h, dim3(256, 1), 0);
+    K.iz = h->d_iz.as<int>();
+    double* in = h->d_vec[0].as<double>(); double* out = h->d_vec[1].as<double>(); double* tmp = h->d_vec[2].as<double>();
+    K.hps = h->d_vec[3].as<double>(); K.p1 = h->d_vec[4].as<double>(); K.p2 = h->d_vec[5].as<double>();
+    XFER(xfer_h2d(h, tmp, psi_in, nd * 8));
+    hipEvent_t e0 = next_event(h);
+    k_block_transpose<true><<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(tmp), reinterpret_cast<double2*>(in));
+    if (vel) kubo_apply_v(K, h->kubo_op[0], in, out);
+    else {
+        kubo_apply_h(K, in, tmp);
+        k_cheb_combine<true><<<(int)std::min<size_t>(4096, (nd + 255) / 256), 256, 0, h->stream>>>(nd, tmp, in, nullptr, out, a, b);
+    }
+    k_block_transpose<false><<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(out), reinterpret_cast<double2*>(tmp));
+    hipEvent_t e1 = next_event(h);
+    HIPCK(h, hipGetLastError());
+    XFER(xfer_d2h(h, psi_out, tmp, nd * 8));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(e0, e1);
+    return RSREC_OK;
 }
 
 extern "C" int rsrec_scalar_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, int llmax, double* a, double* b2) {

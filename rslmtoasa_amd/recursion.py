@@ -252,6 +252,40 @@ class Recursion:
         self._check(self._L.rsrec_chebyshev(self._h, n, _ptr(seeds), lld, a, b, _ptr(mu)))
         self.mu_n[:, :, :, :n] = mu
 
+    def compute_moments_stochastic(self, v_a, v_b, cond_ll, vo_a=None, vo_b=None, seeds=None, coefs=None, atlist=None):
+        """Kubo-Bastin double moments mu_nm_stochastic(18,18,cond_ll,cond_ll,nvec) (recursion.f90:979-1234).
+        ``cond_calctype='per_type'``: pass ``atlist`` (lattice%atlist, one seed atom per type).  Random vectors: pass ``seeds``
+        (nvec, nseed) atoms and ``coefs`` (nvec, nseed) complex (the caller owns the random numbers)."""
+        a, b = chebyshev_scaling(self.en.energy_min, self.en.energy_max)
+        if seeds is None:
+            seeds = np.asarray(atlist, dtype=np.int32).reshape(-1, 1)
+            coefs = np.ones(seeds.shape, np.complex128)
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        coefs = np.ascontiguousarray(coefs, dtype=np.complex128)
+        nvec, nseed = seeds.shape
+        mu = np.zeros((18, 18, cond_ll, cond_ll, nvec), np.complex128, order="F")
+        keep = [None if v is None else _fc(v, np.complex128) for v in (v_a, vo_a, v_b, vo_b)]
+        self._check(self._L.rsrec_kubo_moments(self._h, nvec, nseed, _ptr(seeds), _ptr(coefs), int(cond_ll), a, b,
+                                               _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), _ptr(mu)))
+        self.mu_nm_stochastic = mu
+        return mu
+
+    def ham_vec_matmul(self, psi_in, a, b):
+        """psi_out = (H psi_in - b psi_in)/a on a whole vector psi(18,18,kk) (recursion.f90:913; :785 with hoh)."""
+        x = _fc(psi_in, np.complex128)
+        out = np.zeros_like(x)
+        self._check(self._L.rsrec_apply_operator(self._h, 0, None, None, _ptr(x), _ptr(out), float(a), float(b)))
+        return out
+
+    def velo_vec_matmul(self, v_op, psi_in, vo_op=None):
+        """psi_out = V psi_in (recursion.f90:587; :656 with hoh)."""
+        x = _fc(psi_in, np.complex128)
+        out = np.zeros_like(x)
+        v = _fc(v_op, np.complex128)
+        vo = None if vo_op is None else _fc(vo_op, np.complex128)
+        self._check(self._L.rsrec_apply_operator(self._h, 1, _ptr(v), _ptr(vo), _ptr(x), _ptr(out), 1.0, 0.0))
+        return out
+
     def recur(self):
         """Scalar Haydock recursion, 18 orbital chains per site (recursion.f90:3485-3532)."""
         lld = self.control.lld

@@ -7,7 +7,7 @@ from rslmtoasa_amd.lattice import bcc_supercell, spread_sites
 from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCALARS = ("kk", "nmax", "ntype", "nrec", "lld", "nsp", "hoh", "kind", "nslots", "emin", "emax", "acheb", "bcheb")
+SCALARS = ("kk", "nmax", "ntype", "nrec", "lld", "nsp", "hoh", "kind", "nslots", "emin", "emax", "acheb", "bcheb", "cond_ll")
 
 BLOCK_CASES = ["bccFe_nsp2_block", "bccFe_nsp2_block_hoh", "bccFe_nsp4_block", "B2FeCo_block", "B2FeCo_block_hoh", "fccCu001_block_hoh"]
 CHEB_CASES = ["bccFe_nsp2_cheb", "bccFe_nsp2_cheb_hoh", "fccCu001_cheb"]

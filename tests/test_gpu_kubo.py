@@ -1,0 +1,115 @@
+"""Stochastic Kubo double moments on the GPU: rsrec_kubo_moments and rsrec_apply_operator against the
+compiled reference's compute_moments_stochastic (tests/golden/fccPt_kubo*.npz, oracle/make_fixtures.py run_kubo_case) and the CPU
+oracle.  Error measure: max|mu - ref| over ALL (n, m) blocks of a vector divided by the largest |mu| of that vector -- individual
+(n, m) blocks vanish by symmetry, and the conductivity is a weighted sum over all of them (conductivity.f90 calculate_gamma_nm)."""
+import numpy as np
+import pytest
+
+from helpers import RTOL, load_golden
+from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion
+
+pytestmark = pytest.mark.gpu
+KUBO_CASES = ["fccPt_kubo", "fccPt_kubo_hoh"]
+
+
+def kubo_problem(z):
+    p = {k: z[k] for k in ("nn", "iz", "ee", "lsham", "eeo", "enim") if k in z}
+    p.update(nmax=0, hoh=int(z["hoh"]), nsp=int(z["nsp"]))
+    return p
+
+
+def make_rec(z):
+    p = kubo_problem(z)
+    ham = Hamiltonian(ee=p["ee"], lsham=p["lsham"], eeo=p.get("eeo"), enim=p.get("enim"), hoh=bool(p["hoh"]))
+    lat = Lattice(nn=p["nn"], iz=p["iz"], irec=np.asarray(z["atlist"], np.int32), nmax=0, ntype=p["ee"].shape[3])
+    rec = Recursion(ham, lat, Control(lld=int(z["cond_ll"]), nsp=int(z["nsp"])), Energy(), device=0)
+    return rec, p
+
+
+def scaled(rec, z):
+    """compute_moments_stochastic with the fixture's a, b (the mirror derives them from energy_min / energy_max)."""
+    import rslmtoasa_amd.recursion as R
+    orig = R.chebyshev_scaling
+    R.chebyshev_scaling = lambda emin, emax: (float(z["acheb"]), float(z["bcheb"]))
+    return orig
+
+
+def vec_err(mu, ref):
+    return max(np.abs(mu[..., i] - ref[..., i]).max() / np.abs(ref[..., i]).max() for i in range(ref.shape[-1]))
+
+
+@pytest.mark.parametrize("name", KUBO_CASES)
+def test_kubo_moments_match_reference(name, oracle_lib):
+    z = load_golden(name)
+    rec, p = make_rec(z)
+    import rslmtoasa_amd.recursion as R
+    orig = scaled(rec, z)
+    try:
+        mu = rec.compute_moments_stochastic(z["v_a"], z["v_b"], int(z["cond_ll"]), vo_a=z.get("vo_a"), vo_b=z.get("vo_b"), atlist=z["atlist"])
+    finally:
+        R.chebyshev_scaling = orig
+    assert mu.shape == z["mu_nm"].shape
+    assert vec_err(mu, z["mu_nm"]) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("name", KUBO_CASES)
+def test_kubo_random_vectors_match_oracle(name, oracle_lib):
+    """cond_calctype = 'random_vec' (recursion.f90:1103-1114): every atom carries a random phase / sqrt(kk); two vectors."""
+    z = load_golden(name)
+    rec, p = make_rec(z)
+    kk = p["nn"].shape[0]
+    rng = np.random.default_rng(7)
+    nvec, cond_ll = 2, 5
+    seeds = np.tile(np.arange(1, kk + 1, dtype=np.int32), (nvec, 1))
+    coefs = np.exp(2j * np.pi * rng.random((nvec, kk))) / np.sqrt(kk)
+    import rslmtoasa_amd.recursion as R
+    orig = scaled(rec, z)
+    try:
+        mu = rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, vo_a=z.get("vo_a"), vo_b=z.get("vo_b"), seeds=seeds, coefs=coefs)
+    finally:
+        R.chebyshev_scaling = orig
+    o = oracle_lib.Oracle(p)
+    ref = o.kubo_moments(seeds, coefs, cond_ll, float(z["acheb"]), float(z["bcheb"]), z["v_a"], z["v_b"], z.get("vo_a"), z.get("vo_b"))
+    assert vec_err(mu, ref) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("name", KUBO_CASES)
+def test_whole_vector_products_compose_to_the_moments(name):
+    """ham_vec_matmul / velo_vec_matmul on caller arrays (rsrec_apply_operator): building the first moments by hand from them
+    gives what rsrec_kubo_moments returns (and so, by the test above, the reference's numbers)."""
+    z = load_golden(name)
+    rec, p = make_rec(z)
+    a, b = float(z["acheb"]), float(z["bcheb"])
+    kk = p["nn"].shape[0]
+    j = int(z["atlist"][0]) - 1
+    psiref = np.zeros((18, 18, kk), np.complex128, order="F")
+    psiref[np.arange(18), np.arange(18), j] = 1.0
+    vo_a, vo_b = z.get("vo_a"), z.get("vo_b")
+    left = [psiref, rec.ham_vec_matmul(psiref, a, b)]
+    v0 = rec.velo_vec_matmul(z["v_b"], psiref, vo_b)
+    rights = [rec.velo_vec_matmul(z["v_a"], v0, vo_a), rec.velo_vec_matmul(z["v_a"], rec.ham_vec_matmul(v0, a, b), vo_a)]
+    ref = z["mu_nm"][:, :, :2, :2, 0]
+    scale = np.abs(z["mu_nm"]).max()
+    for n in range(2):
+        for m in range(2):
+            mu = np.einsum("rck,rdk->cd", left[m].conj(), rights[n])
+            assert np.abs(mu - ref[:, :, n, m]).max() < RTOL * scale
+    # linearity of the product
+    x = np.asfortranarray(np.random.default_rng(3).standard_normal((18, 18, kk)) + 0j)
+    y1 = rec.ham_vec_matmul(x, a, b)
+    y2 = rec.ham_vec_matmul(2.5 * x, a, b)
+    assert np.abs(y2 - 2.5 * y1).max() < 1e-12 * np.abs(y1).max()
+    rec.close()
+
+
+def test_kubo_argument_errors():
+    from rslmtoasa_amd import _lib
+    z = load_golden("fccPt_kubo_hoh")
+    rec, p = make_rec(z)
+    with pytest.raises(_lib.RsrecError):                      # hoh needs vo_a / vo_b
+        rec.compute_moments_stochastic(z["v_a"], z["v_b"], 3, atlist=z["atlist"])
+    with pytest.raises(_lib.RsrecError):                      # seed atom outside the lattice
+        rec.compute_moments_stochastic(z["v_a"], z["v_b"], 3, vo_a=z["vo_a"], vo_b=z["vo_b"], atlist=[p["nn"].shape[0] + 1])
+    rec.close()
