@@ -85,6 +85,17 @@ int rsrec_block_lanczos(rsrec_t *h, int nsites, const int32_t *seed_atoms, int l
 int rsrec_block_lanczos_seeded(rsrec_t *h, int nchains, int nseed, const int32_t *seed_atoms, const double *seed_coef,
                                int lld, double *a_b, double *b2_b);
 
+/* recur_b with hamiltonian%local_axis = T (non-collinear runs, recursion.f90:1830-1832), every site in ONE batched call.
+ * The reference rotates all blocks into the spin frame of site i's moment before that site's chain (rotate_to_local_axis,
+ * hamiltonian.f90:2442-2465: ee, hall, eeo, hallo, enim -- NOT lsham) and runs the sites one after the other.  Here the
+ * operator is set ONCE in the GLOBAL frame (rsrec_set_hamiltonian with ee_glob, hall_glob, eeo_glob, hallo_glob, enim_glob and
+ * lsham) and every chain carries its rotation:
+ *   rot : complex (18,18,nsites), R_i = ROTMAT(alpha_i, beta_i, 0) of site i's moment direction (math.f90:2026, car2sph :2155)
+ * The chain of the rotated operator equals the chain of the global operator with the on-site term R_i l.s R_i^H, conjugated:
+ * a_b(:,:,:,i) = R_i^H A R_i, b2_b likewise -- the library does both; outputs are in the local frame of each site like the
+ * reference's.  a_b, b2_b : complex (18,18,lld,nsites) out. */
+int rsrec_block_lanczos_local_axis(rsrec_t *h, int nsites, const int32_t *seed_atoms, const double *rot, int lld, double *a_b, double *b2_b);
+
 /* The per-site result the ranks exchange after the recursion, packed ON THE DEVICE from the coefficients the last
  * rsrec_block_lanczos call left there: a(ll,l,site) = Re a_b(l,l,ll,site), b2 likewise (recursion.f90:1850-1851).
  * The reference gathers per-site arrays with MPI_ALLREDUCE(MPI_IN_PLACE, ..., MPI_SUM) on zero-padded images

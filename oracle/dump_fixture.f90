@@ -210,6 +210,38 @@ program dump_fixture
       write (u) recursion_obj%b2(:, :, :, 1)
    end select
    close (u)
+   ! ---- local_axis = T (recursion.f90:1830-1832): the chain of site i ran on the blocks rotated into the spin frame of that
+   !      site's moment (hamiltonian.f90:2442-2465); the arrays dumped above are in the LAST site's frame.  The global-frame
+   !      blocks the rotation starts from, the moment directions and the rotation matrices ROTMAT(car2sph(mom)) (math.f90:2026)
+   !      go to a side file.
+   if (hamiltonian_obj%local_axis) call dump_local_axis()
    write (*, *) 'dump_fixture: wrote fixture.bin kk=', lattice_obj%kk, ' nmax=', lattice_obj%nmax, ' nrec=', lattice_obj%nrec, &
       ' lld=', control_obj%lld, ' nslots=', nslots, ' kind=', kind_rec, ' hoh=', hoh_i
+contains
+   subroutine dump_local_axis()
+      use math_mod, only: car2sph, ROTMAT
+      integer :: v, is
+      real(rp) :: sv(3), mom(3)
+      complex(rp) :: rmat(18, 18)
+      open (newunit=v, file='local_axis.bin', access='stream', form='unformatted', status='replace')
+      write (v) int(z'4c415831'), lattice_obj%nrec
+      write (v) hamiltonian_obj%ee_glob
+      if (hamiltonian_obj%hoh) then
+         write (v) hamiltonian_obj%eeo_glob
+         write (v) hamiltonian_obj%enim_glob
+      end if
+      if (lattice_obj%nmax > 0) then
+         write (v) hamiltonian_obj%hall_glob
+         if (hamiltonian_obj%hoh) write (v) hamiltonian_obj%hallo_glob
+      end if
+      do is = 1, lattice_obj%nrec
+         mom = lattice_obj%symbolic_atoms(is)%potential%mom
+         call car2sph(mom, sv)
+         rmat = (0.0_rp, 0.0_rp)
+         call ROTMAT(rmat, sv(1), sv(2), 0.0_rp)
+         write (v) mom
+         write (v) rmat
+      end do
+      close (v)
+   end subroutine dump_local_axis
 end program dump_fixture

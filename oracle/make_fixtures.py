@@ -55,6 +55,12 @@ CASES = {
     "fccCu001_nsp1_lanczos": ("tests/scf/cases/surface/fccCu001", {"control": {"nsp": 1, "recur": "'lanczos'", "lld": 12, "llsp": 12}, "hamiltonian": {"hoh": ".false."}}),
     "B2FeCo_nsp1_lanczos": ("tests/scf/cases/impurity/B2FeCo", {"control": {"nsp": 1, "recur": "'lanczos'", "lld": 12, "llsp": 12}, "hamiltonian": {"hoh": ".false."}}),
 }
+# non-collinear run with per-site spin frames (hamiltonian%local_axis = T, recursion.f90:1830-1832): four sites (Mn, Ga, Pt1, Pt2)
+# whose moment directions are set to four different axes in the atoms' potential files (MOM_PATCH)
+CASES["Pt2MnGa_nsp4_local_axis"] = ("tests/scf/cases/bulk/Pt2MnGa", {"control": {"nsp": 4, "recur": "'block'", "lld": 10}, "hamiltonian": {"hoh": ".false.", "local_axis": ".true."}})
+CASES["Pt2MnGa_nsp4_local_axis_hoh"] = ("tests/scf/cases/bulk/Pt2MnGa", {"control": {"nsp": 4, "recur": "'block'", "lld": 10}, "hamiltonian": {"hoh": ".true.", "local_axis": ".true."}})
+MOM_PATCH = {"Pt2MnGa_nsp4_local_axis": {"Mn.nml": (0.6, 0.0, 0.8), "Ga.nml": (0.0, 0.0, 1.0), "Pt1.nml": (0.0, 0.8, 0.6), "Pt2.nml": (-0.36, 0.48, 0.8)}}
+MOM_PATCH["Pt2MnGa_nsp4_local_axis_hoh"] = MOM_PATCH["Pt2MnGa_nsp4_local_axis"]
 OUTPUTS_ONLY = {"fccCu001_cheb50": "fccCu001_cheb"}      # name -> fixture that holds the (identical) inputs
 # Green-function-only variants: same recursion inputs as the base case (tests pair them with <base>.npz), other terminator options
 GREEN_ONLY = {
@@ -99,6 +105,10 @@ def run_case(name):
         p = os.path.join(scratch, "input.nml")
         txt = patch_namelist(open(p).read(), patch)
         open(p, "w").write(txt)
+        for fn, mom in MOM_PATCH.get(name, {}).items():
+            q = os.path.join(scratch, fn)
+            t = re.sub(r"(?im)^(\s*mom\s*=\s*)[^\n]*", lambda mm: mm.group(1) + "%.16g, %.16g, %.16g" % mom, open(q).read(), count=1)
+            open(q, "w").write(t)
         cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_fixture.x")
         r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "fixture.bin")):
@@ -106,6 +116,28 @@ def run_case(name):
             raise RuntimeError("dump_fixture failed for " + name)
         d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
         extra = {"source_case": np.array(case_dir), "namelist_patch": np.array(repr(patch))}
+        la = os.path.join(scratch, "local_axis.bin")
+        if os.path.exists(la):
+            # global-frame blocks replace the (last site's frame) arrays of fixture.bin; moments and rotation matrices are added
+            import struct
+            with open(la, "rb") as f:
+                magic, nrec = struct.unpack("<ii", f.read(8))
+                assert magic == 0x4c415831 and nrec == d["nrec"]
+                d["ee"] = fio._rd(f, np.complex128, d["ee"].shape)
+                if d["hoh"]:
+                    d["eeo"] = fio._rd(f, np.complex128, d["eeo"].shape)
+                    d["enim"] = fio._rd(f, np.complex128, d["enim"].shape)
+                if d["nmax"] > 0:
+                    d["hall"] = fio._rd(f, np.complex128, d["hall"].shape)
+                    if d["hoh"]:
+                        d["hallo"] = fio._rd(f, np.complex128, d["hallo"].shape)
+                moms, rots = [], []
+                for _ in range(nrec):
+                    moms.append(fio._rd(f, np.float64, (3,)))
+                    rots.append(fio._rd(f, np.complex128, (18, 18)))
+                assert f.read(1) == b""
+            extra.update(local_axis=np.array(1), mom=np.stack(moms, axis=1), rot=np.stack(rots, axis=2), mom_patch=np.array(repr(MOM_PATCH.get(name))))
+            d.pop("green", None)
         if name == "bccFe_nsp2_block":
             extra["slot_vec"] = slot_vectors(d)
         if name in OUTPUTS_ONLY:

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "rsrec_set_hamiltonian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "rsrec_block_lanczos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "rsrec_block_lanczos_local_axis": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_pack_diag": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_terminator": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "rsrec_block_ldos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),

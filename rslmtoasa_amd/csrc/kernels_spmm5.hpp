@@ -252,7 +252,7 @@ __device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Sing
 // TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot of the hoh second pass; it reads the second
 // input vector in2b (recursion.f90:1543: H psi = h psi - (h o)(h psi) + (e_nu + l.s) psi, the last term acts on psi itself).
 template <bool TWO>
-__device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const char* __restrict__ inb,
+__device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ fr_extra, const char* __restrict__ inb,
                                              const char* __restrict__ in2b, const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
                                              int nslots, int sig,
@@ -276,7 +276,12 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
         S.rem = (unsigned)nr * (BLD * 8u);
     };
     const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB);
-    auto frag_of = [&](int s, int si) { return reinterpret_cast<const char*>(fr_sig + (size_t)s * S5_FRAG_PER_SLOT + si * (5 * S5_FRAG_PER_RB)); };
+    // fr_extra (TWO only, may be null): fragments of the extra on-site slot taken from a per-chain table instead of the shared one
+    const double* __restrict__ fx_sig = (TWO && fr_extra) ? fr_extra + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB) - (size_t)nslots * S5_FRAG_PER_SLOT : fr_sig;
+    auto frag_of = [&](int s, int si) {
+        const double* __restrict__ base = (TWO && s == nslots) ? fx_sig : fr_sig;
+        return reinterpret_cast<const char*>(base + (size_t)s * S5_FRAG_PER_SLOT + si * (5 * S5_FRAG_PER_RB));
+    };
     auto spin_of = [&](int e) { return (e >> 8) ? 1 - sig : sig; };
     S5Slot cur;
     int nraw[GROUP], nrem;
@@ -317,13 +322,15 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  Input and output vectors in the CI layout.
-// TWO: second input vector for the extra on-site slot (second pass of hoh).
+// TWO: second input vector for the extra on-site slot (second pass of hoh; the per-chain on-site term of local-axis runs).
 template <bool TWO>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
-                                               const double* __restrict__ in2_all = nullptr) {
+                                               const double* __restrict__ in2_all = nullptr,
+                                               const double* __restrict__ frag_extra = nullptr /*[chain][tau][S5_FRAG_PER_SLOT]: per-chain extra-slot operator*/,
+                                               int ntau = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
 
-        s5_run_slots<TWO>(acc, M, fr, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        const double* __restrict__ fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * S5_FRAG_PER_SLOT : nullptr;
+        s5_run_slots<TWO>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
         // D layout: real-form row rho = 4 rb + l4 of spin sig, column l15.  rb = 2 P + e is (part e, m = 4 P + l4): the accumulators
         // (2P, 2P+1) are the real and imaginary part of element (m, c) -> one 16-byte store in the CI layout; rb = 4: m = 8

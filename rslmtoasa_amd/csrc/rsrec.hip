@@ -83,7 +83,9 @@ struct rsrec_handle {
     int s4_built_split = 0;
     Spmm5Operator s5_op;
     int s5_built = 0;
-    std::vector<double> host_ee;       // ee as last set (the hoh velocity product needs h restricted to the bulk atoms)
+    std::vector<double> host_ee, host_lsham, host_eeo, host_enim, host_hall, host_hallo;   // operator arrays as last set (Kubo operator tables; local-axis runs)
+    Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
+    DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
     void* rocblas_lib = nullptr; void* rocblas_handle = nullptr;
     // work
@@ -322,7 +324,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     h->mfma_op.release();
     h->s4_op.release();
     h->s5_op.release();
-    h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release();
+    h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release(); h->s5_la.release(); h->d_la_extra.release();
     if (h->rocblas_handle && g_rocblas_destroy) g_rocblas_destroy(h->rocblas_handle);
     if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
@@ -476,6 +478,11 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
     const int ntype = h->ntype, nmax = h->nmax;
     h->hslots = nslots; h->hoh = hoh ? 1 : 0; h->nsp = nsp;
     h->host_ee.assign(ee, ee + 2 * (size_t)BLK * nslots * h->ntype);
+    h->host_lsham.assign(lsham, lsham + 2 * (size_t)BLK * h->ntype);
+    h->host_eeo.clear(); h->host_enim.clear(); h->host_hall.clear(); h->host_hallo.clear();
+    if (hoh) { h->host_eeo.assign(eeo, eeo + 2 * (size_t)BLK * nslots * h->ntype); h->host_enim.assign(enim, enim + 2 * (size_t)BLK * h->ntype); }
+    if (h->nmax > 0) { h->host_hall.assign(hall, hall + 2 * (size_t)BLK * nslots * h->nmax); if (hoh) h->host_hallo.assign(hallo, hallo + 2 * (size_t)BLK * nslots * h->nmax); }
+    h->s5_la_ok = 0;
     // stencil with the on-site spin-orbit block folded into slot 0 (locham = ee(:,:,1,ih) + lsham(:,:,ih), recursion.f90:1608)
     std::vector<double> st(ee, ee + B * nslots * ntype);
     if (!hoh)
@@ -794,7 +801,8 @@ int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevPr
 
 // One implementation for both kernel sets: L = LayoutCM with the VALU kernels, LayoutRM with the MFMA SpMM.
 template <class L, bool MFMA>
-int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld, double* a_b, double* b2_b) {
+int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_atoms, const double* seed_coef, int lld, double* a_b, double* b2_b,
+                      const double* rot = nullptr /*local-axis runs: complex (18,18,nchains), the spin-frame rotation of every chain*/) {
     const int kk = h->kk;
     const bool hoh = h->hoh != 0;
     const int nsteps = lld - 1;
@@ -806,11 +814,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     // large launches: k_spmm5 with every vector in the CI layout; small launches keep the cooperative k_spmm4<4> on LayoutRM
     // (spmm5 = 2 forces k_spmm5)
     const bool use_kp = u_scheme && h->s5_built && h->opt_spmm4 != 0 &&
-                        (h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
+                        (rot || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
     // hoh on the un-normalised scheme: both SpMM passes in k_spmm5 (first pass writes KP, second pass adds the on-site
     // e_nu + l.s term from psi through its extra slot), then the same post-hop kernels as without hoh
     const bool u_hoh = MFMA && hoh && h->opt_post != 1 && h->opt_three == 2 && h->opt_wps != 2 && h->s5_built && h->opt_spmm5 >= 1 && h->opt_spmm4 != 0;
     const int ci = (use_kp || u_hoh) ? 1 : 0;                 // vectors of this call are CI (else LayoutRM / LayoutCM)
+    if (rot && !(MFMA && ci)) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set with k_spmm5 (options kernels / spmm5 / three_term at their defaults)");
+    const int ntau = h->nmax + h->ntype;
+    const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
+    if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * S5_FRAG_PER_SLOT * sizeof(double)));
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -870,6 +882,40 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         if (rc) return rc;
         XFER(xfer_h2d(h, h->d_seed.p, seeds0.data(), seeds0.size() * 4));
         XFER(xfer_h2d(h, h->d_seedcoef.p, coef.data(), coef.size() * 8));
+        const double* la_extra = nullptr;
+        if (rot) {
+            // per-chain on-site term of the local-axis operator in the GLOBAL frame: (e_nu +) R l.s R^H  (see rsrec_block_lanczos_local_axis)
+            std::vector<double> fr((size_t)nb * ntau * S5_FRAG_PER_SLOT), E(2 * BLK), T(2 * BLK);
+            for (int c = 0; c < nb; ++c) {
+                const double* R = rot + 2 * (size_t)BLK * (c0 + c);
+                for (int tau = 0; tau < ntau; ++tau) {
+                    const int ty = tau < h->nmax ? h->iz0[tau] : tau - h->nmax;
+                    const double* ls = h->host_lsham.data() + 2 * (size_t)BLK * ty;
+                    for (int j = 0; j < NB; ++j)                    // T = l.s R^H
+                        for (int i = 0; i < NB; ++i) {
+                            double sr = 0.0, si = 0.0;
+                            for (int k = 0; k < NB; ++k) {
+                                const double ar = ls[2 * (i + NB * k)], ai = ls[2 * (i + NB * k) + 1], br = R[2 * (j + NB * k)], bi = -R[2 * (j + NB * k) + 1];
+                                sr += ar * br - ai * bi; si += ar * bi + ai * br;
+                            }
+                            T[2 * (i + NB * j)] = sr; T[2 * (i + NB * j) + 1] = si;
+                        }
+                    for (int j = 0; j < NB; ++j)                    // E = R T
+                        for (int i = 0; i < NB; ++i) {
+                            double sr = 0.0, si = 0.0;
+                            for (int k = 0; k < NB; ++k) {
+                                const double ar = R[2 * (i + NB * k)], ai = R[2 * (i + NB * k) + 1], br = T[2 * (k + NB * j)], bi = T[2 * (k + NB * j) + 1];
+                                sr += ar * br - ai * bi; si += ar * bi + ai * br;
+                            }
+                            E[2 * (i + NB * j)] = sr; E[2 * (i + NB * j) + 1] = si;
+                        }
+                    if (hoh) for (int e = 0; e < 2 * BLK; ++e) E[e] += h->host_enim[2 * (size_t)BLK * ty + e];
+                    Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * S5_FRAG_PER_SLOT);
+                }
+            }
+            XFER(xfer_h2d(h, h->d_la_extra.p, fr.data(), fr.size() * sizeof(double)));
+            la_extra = h->d_la_extra.as<double>();
+        }
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
 
@@ -935,6 +981,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                         continue;
                     }
                     if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
+                    else if (use_kp && rot) k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi, psi, la_extra, ntau);
                     else if (use_kp) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), psi, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                     e1 = next_event(h);
@@ -983,9 +1030,9 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 double* hps = pmn;                       // the pmn buffer is free in the u-scheme: h psi of the first pass
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), psi, hps);
+                k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hps);
                 SD.level = lv_final;
-                k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hps, hpsi, psi);
+                k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(1), OP.meta_set(1), hps, hpsi, psi, la_extra, ntau);
                 e1 = next_event(h);
                 k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
@@ -1066,6 +1113,92 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
 
 extern "C" int rsrec_block_lanczos(rsrec_t* h, int nsites, const int32_t* seed_atoms, int lld, double* a_b, double* b2_b) {
     return rsrec_block_lanczos_seeded(h, nsites, 1, seed_atoms, nullptr, lld, a_b, b2_b);
+}
+
+namespace {
+
+// Operator tables of a local-axis run: the blocks as set (GLOBAL spin frame), on-site slot WITHOUT l.s; the l.s term (with e_nu for
+// hoh) enters through the extra on-site slot whose fragments come per chain.  The placeholder only makes the slot appear in the
+// schedule with both spin parts.
+int build_local_axis_operator(rsrec_t* h) {
+    if (h->s5_la_ok) return RSREC_OK;
+    const int ntau = h->nmax + h->ntype, nfs = h->nslots + 1, nset = h->hoh ? 2 : 1;
+    const size_t B = 2 * (size_t)BLK;
+    std::vector<const double*> blk((size_t)nset * ntau * nfs, nullptr);
+    std::vector<double> dense(B, 1.0), neg((size_t)ntau * h->nslots * B, 0.0);
+    for (int tau = 0; tau < ntau; ++tau) {
+        for (int s = 0; s < h->nslots; ++s) {
+            const double* src = tau < h->nmax ? h->host_hall.data() + B * (s + (size_t)h->hslots * tau) : h->host_ee.data() + B * (s + (size_t)h->hslots * (tau - h->nmax));
+            blk[((size_t)0 * ntau + tau) * nfs + s] = src;
+            if (nset > 1) {
+                const double* so = tau < h->nmax ? h->host_hallo.data() + B * (s + (size_t)h->hslots * tau) : h->host_eeo.data() + B * (s + (size_t)h->hslots * (tau - h->nmax));
+                double* d = neg.data() + B * (s + (size_t)h->nslots * tau);
+                for (size_t e = 0; e < B; ++e) d[e] = -so[e];
+                if (s == 0) for (int q = 0; q < NB; ++q) d[2 * (q + NB * q)] += 1.0;
+                blk[((size_t)1 * ntau + tau) * nfs + s] = d;
+            }
+        }
+        blk[((size_t)(nset - 1) * ntau + tau) * nfs + h->nslots] = dense.data();
+    }
+    const char* msg = h->s5_la.build_custom(h->nslots, ntau, nset, blk);
+    if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_block_lanczos_local_axis: %s", msg);
+    h->s5_la_ok = 1;
+    return RSREC_OK;
+}
+
+}  // namespace
+
+// recur_b with hamiltonian%local_axis = T (recursion.f90:1830-1832), all sites in one batched call.  The reference rotates every
+// block into the spin frame of site i's moment before that site's chain, H'_i = R_i^H H R_i blockwise -- except the on-site l.s term,
+// which rotate_to_local_axis (hamiltonian.f90:2442-2465) leaves alone.  With phi = R_i psi (blocks multiplied from the left) the
+// chain of H'_i from the seed 1 is the chain of  H''_i = H + onsite(R_i l.s R_i^H - l.s)  from the seed R_i, i.e. from the seed 1
+// followed by a right-multiplication with the unitary R_i:   A'_n = R_i^H A''_n R_i,  B'^2_n = R_i^H B''^2_n R_i.
+// So every chain runs on the SAME global-frame blocks and differs only in its on-site term (per-chain extra slot of k_spmm5); the
+// 18x18 outputs are conjugated on the host.  Checked against the compiled reference on four sites with four moment directions.
+extern "C" int rsrec_block_lanczos_local_axis(rsrec_t* h, int nsites, const int32_t* seed_atoms, const double* rot, int lld, double* a_b, double* b2_b) {
+    int rc = check_ready(h, "rsrec_block_lanczos_local_axis");
+    if (rc) return rc;
+    if (nsites < 0 || lld < 1 || !a_b || !b2_b || (nsites > 0 && (!seed_atoms || !rot))) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos_local_axis: bad argument");
+    for (int q = 0; q < nsites; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos_local_axis: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    if (!h->s5_built) return fail(h, RSREC_ERR_ARG, "rsrec_block_lanczos_local_axis: lattice has too many neighbour slots for the SpMM kernel");
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    if (nsites == 0) return RSREC_OK;
+    rc = build_local_axis_operator(h); if (rc) return rc;
+    rc = run_block_lanczos<LayoutRM, true>(h, nsites, 1, seed_atoms, nullptr, lld, a_b, b2_b, rot);
+    if (rc) return rc;
+    // A' = R^H A R, B'^2 = R^H B^2 R; b2_b(:,:,1) = I and a_b(:,:,lld) = 0 stay exact (recursion.f90:1836-1837)
+    std::vector<double> T(2 * BLK);
+    auto conj_sim = [&](double* M, const double* R) {
+        for (int j = 0; j < NB; ++j)
+            for (int i = 0; i < NB; ++i) {
+                double sr = 0.0, si = 0.0;
+                for (int k = 0; k < NB; ++k) {
+                    const double ar = M[2 * (i + NB * k)], ai = M[2 * (i + NB * k) + 1], br = R[2 * (k + NB * j)], bi = R[2 * (k + NB * j) + 1];
+                    sr += ar * br - ai * bi; si += ar * bi + ai * br;
+                }
+                T[2 * (i + NB * j)] = sr; T[2 * (i + NB * j) + 1] = si;
+            }
+        for (int j = 0; j < NB; ++j)
+            for (int i = 0; i < NB; ++i) {
+                double sr = 0.0, si = 0.0;
+                for (int k = 0; k < NB; ++k) {
+                    const double ar = R[2 * (k + NB * i)], ai = -R[2 * (k + NB * i) + 1], br = T[2 * (k + NB * j)], bi = T[2 * (k + NB * j) + 1];
+                    sr += ar * br - ai * bi; si += ar * bi + ai * br;
+                }
+                M[2 * (i + NB * j)] = sr; M[2 * (i + NB * j) + 1] = si;
+            }
+    };
+    for (int s = 0; s < nsites; ++s) {
+        const double* R = rot + 2 * (size_t)BLK * s;
+        for (int ll = 0; ll < lld; ++ll) {
+            if (ll < lld - 1) conj_sim(a_b + 2 * (size_t)BLK * ((size_t)s * lld + ll), R);
+            if (ll > 0) conj_sim(b2_b + 2 * (size_t)BLK * ((size_t)s * lld + ll), R);
+        }
+    }
+    h->res_kind = 0;          // the resident coefficients are the un-rotated ones: not valid input for the LDOS stage
+    return RSREC_OK;
 }
 
 namespace {

@@ -188,6 +188,22 @@ class Recursion:
         self.a[:lld, :, :n, 0] = a_b[d, d].real.transpose(1, 0, 2)    # :1850-1851
         self.b2[:lld, :, :n, 0] = b2_b[d, d].real.transpose(1, 0, 2)
 
+    def recur_b_local_axis(self, rot):
+        """recur_b with hamiltonian%local_axis = T (recursion.f90:1830-1832): the Hamiltonian object holds the GLOBAL-frame blocks
+        (ee_glob, ...), ``rot`` (18,18,nrec) the spin-frame rotation of every site; all sites go in one batched call."""
+        lld = self.control.lld
+        start, end, seeds = self._my_sites()
+        n = len(seeds)
+        r = _fc(np.asarray(rot)[:, :, start - 1:end], np.complex128)
+        a_b = np.zeros((18, 18, lld, n), np.complex128, order="F")
+        b2_b = np.zeros_like(a_b)
+        self._check(self._L.rsrec_block_lanczos_local_axis(self._h, n, _ptr(seeds), _ptr(r), lld, _ptr(a_b), _ptr(b2_b)))
+        self.a_b[:, :, :, :n] = a_b
+        self.b2_b[:, :, :, :n] = b2_b
+        d = np.arange(18)
+        self.a[:lld, :, :n, 0] = a_b[d, d].real.transpose(1, 0, 2)
+        self.b2[:lld, :, :n, 0] = b2_b[d, d].real.transpose(1, 0, 2)
+
     def pack_diag(self, site_offset, nsites_total, a_img, b2_img):
         """This rank's part of the zero-padded (lld, 18, nsites_total) images of a / b2 that the ranks all-reduce
         (bands.f90:271-274), written from the coefficients resident on the device.  a_img / b2_img: numpy arrays or raw

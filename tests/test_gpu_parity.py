@@ -260,3 +260,25 @@ def test_errors_are_loud():
         rec.chebyshev_recur()
     assert ei.value.code == ERR_DIVERGED and "did not converge" in str(ei.value)
     rec.close()
+
+
+@pytest.mark.parametrize("name", ["Pt2MnGa_nsp4_local_axis", "Pt2MnGa_nsp4_local_axis_hoh"])
+def test_local_axis_batched_block_lanczos(name):
+    """hamiltonian%local_axis = T (recursion.f90:1830-1832): four sites (Mn, Ga, Pt1, Pt2) with four different moment directions,
+    every chain in ITS spin frame.  The reference rotates all blocks per site and runs the sites one by one; here all four chains
+    go in one call on the global-frame blocks (per-chain on-site l.s term + conjugation of the outputs).  Fixture: the compiled
+    reference's coefficients in each site's local frame, its global-frame blocks and rotation matrices."""
+    g = load_golden(name)
+    assert int(g["local_axis"]) == 1 and g["nrec"] == 4
+    moms = g["mom"].T
+    assert len({tuple(np.round(m, 6)) for m in moms}) == 4                 # four inequivalent directions
+    rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
+    rec.recur_b_local_axis(g["rot"])
+    n = g["nrec"]
+    assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL
+    assert rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]) < RTOL
+    assert np.all(rec.a_b[:, :, -1] == 0) and np.array_equal(rec.b2_b[:, :, 0, 0], np.eye(18))
+    # running in the global frame instead (what a run without local_axis would give) is a DIFFERENT result for the tilted sites
+    rec.recur_b()
+    assert rel_err(rec.a_b[:, :, :, :1], g["a_b"][:, :, :, :1]) > 1e-6
+    rec.close()
