@@ -7,9 +7,9 @@
 ! DESCRIPTION:
 !> `type, extends(green) :: green_gpu` overrides the continued fraction of the reference's `green` type, `bgreen` (and its all-sites driver `block_green`, to batch the sites)
 !> (green.f90:1191-1339), the continued fraction  coefficients -> g(E)  that `block_green` (:588), `block_green_eta`
-!> (:541) and the inter-site variants call per site.  Everything else -- the terminator (`recursion%get_terminf`, CPU),
+!> (:541) and the inter-site variants call per site.  Everything else -- the terminator (`recursion%get_terminf`),
 !> the result arrays `g0, gij, ...`, `sgreen`, `chebyshev_green` -- is inherited.  The GPU side is `rsrec_block_green`
-!> (include/rsrec.h): one wave per energy point, 18x18 complex inverse with LAPACK's pivot rule, in LDS.
+!> (include/rsrec.h): one wave per energy point, register-resident 18x18 complex inverse with LAPACK's pivot rule (LDS carries only pivot rows / columns).
 !>
 !> `bands`, `self` and `exchange` hold `class(green), pointer` (bands.f90:49, self.f90:76, exchange.f90:48); the only
 !> non-polymorphic spot is the dummy of the `bands` constructor (bands.f90:121, `type(green), target`), which a maintainer
@@ -94,7 +94,7 @@ contains
 
    !> Replaces green.f90:588-621: the per-site loop over `bgreen` becomes ONE library call for all sites of this rank, so the
    !> kernel of one chunk of sites overlaps the download of the previous one (rsrec.hip green_pipeline) instead of a
-   !> launch + 13 MB copy per site.  Terminator exactly as the reference computes it (get_terminf stays on the CPU).
+   !> launch + 13 MB copy per site.  The terminator comes from recursion%get_terminf (GPU kernel behind recursion_gpu).
    subroutine gpu_block_green(this)
       use mpi_mod, only: start_atom, end_atom, g2l_map, atoms_per_process
       class(green_gpu), intent(inout) :: this
@@ -112,18 +112,14 @@ contains
       nloc = end_atom - start_atom + 1
       if (nloc <= 0) return
       n1 = g2l_map(start_atom)                               ! local indices of the rank's sites are contiguous (mpi.f90:72-78)
-      ! Terminator: the reference's own routine (recursion.f90:2092), one call per site instead of one call looping over the
-      ! sites -- every site is independent and get_terminf / get_cinf / bpopt / emami work on their arguments and locals only,
-      ! so the calls can run on the host threads in parallel (13 ms per site at lld = 50: 0.8 s for 64 sites if done serially,
-      ! more than the recursion and the Green function of those sites take on the GPU together).
+      ! Terminator: ONE get_terminf call for all sites of the rank (recursion.f90:2092).  With a recursion_gpu behind the class
+      ! pointer this dispatches to the terminator kernel (one thread per site and matrix element, rsrec_terminator); with the
+      ! reference's own type it is the reference's serial loop over the sites.
       a_inf = 0.0_rp; b_inf = 0.0_rp
-      !$omp parallel do default(shared) private(n, nw_site) schedule(dynamic, 1)
-      do n = n1, n1 + nloc - 1
-         nw_site = nw
-         call this%recursion%get_terminf(this%recursion%a_b(:, :, :, n:n), this%recursion%b2_b(:, :, :, n:n), 1, &
-                                         ll, ldim, nw_site, a_inf(:, :, n:n), b_inf(:, :, n:n), a_inf0(n:n), b_inf0(n:n))
-      end do
-      !$omp end parallel do
+      nw_site = nw
+      call this%recursion%get_terminf(this%recursion%a_b(:, :, :, n1:n1 + nloc - 1), this%recursion%b2_b(:, :, :, n1:n1 + nloc - 1), nloc, &
+                                      ll, ldim, nw_site, a_inf(:, :, n1:n1 + nloc - 1), b_inf(:, :, n1:n1 + nloc - 1), &
+                                      a_inf0(n1:n1 + nloc - 1), b_inf0(n1:n1 + nloc - 1))
       nv = this%en%channels_ldos + 10
       allocate (ene(nv), ai(18, 18, nloc), bi(18, 18, nloc), ab(18, 18, ll, nloc), bs(18, 18, ll, nloc))
       ene = this%en%ene(1:nv)

@@ -4,9 +4,10 @@
 ! `type(recursion_gpu)` EXTENDS the reference's `type(recursion)` (source/recursion.f90:41-116) and overrides
 ! exactly the hot-path type-bound procedures
 !     recur_b (:1807)   recur_b_ij (:1655)   chebyshev_recur (:3057)   chebyshev_recur_ij (:2376)   recur (:3485)   zsqr (:1980)
+!     get_terminf (:2092)   compute_moments_stochastic (:979)   ham_[hoh_]vec_matmul (:913/:785)   velo_[hoh_]vec_matmul (:587/:656)
 ! with calls into librsrec (hand-written HIP kernels behind the C ABI of include/rsrec.h).  Everything else --
-! data members a, b2, a_b, b2_b, mu_n (same shapes, same index order), the terminator routines get_terminf / bpopt /
-! emami used by green.f90 and density_of_states.f90, restore_to_default -- is inherited unchanged, and every consumer
+! data members a, b2, a_b, b2_b, mu_n (same shapes, same index order), bpopt / emami / get_cinf (the scalar-chain terminator of
+! density_of_states.f90), setup_kubo_operators, chebyshev_orbital_mod, restore_to_default -- is inherited unchanged, and every consumer
 ! in the reference holds a `class(recursion), pointer` (self.f90:64, green.f90:45, density_of_states.f90:44,
 ! bands.f90:61), so the SCF loop dispatches to the GPU drivers without being edited.  The only edit a maintainer makes
 ! is the declaration/constructor in calculation.f90 (see INTEGRATION.md):
@@ -26,7 +27,7 @@ module recursion_gpu_mod
    use energy_mod
    use recursion_mod
    use precision_mod, only: rp
-   use math_mod, only: one_over_sqrt_two
+   use math_mod, only: one_over_sqrt_two, car2sph, ROTMAT
    use string_mod, only: int2str
    use logger_mod, only: g_logger
    use timer_mod, only: g_timer
@@ -43,6 +44,12 @@ module recursion_gpu_mod
       procedure :: chebyshev_recur => gpu_chebyshev_recur
       procedure :: chebyshev_recur_ij => gpu_chebyshev_recur_ij
       procedure :: zsqr => gpu_zsqr
+      procedure :: get_terminf => gpu_get_terminf
+      procedure :: compute_moments_stochastic => gpu_compute_moments_stochastic
+      procedure :: ham_vec_matmul => gpu_ham_vec_matmul
+      procedure :: ham_hoh_vec_matmul => gpu_ham_hoh_vec_matmul
+      procedure :: velo_vec_matmul => gpu_velo_vec_matmul
+      procedure :: velo_hoh_vec_matmul => gpu_velo_hoh_vec_matmul
    end type recursion_gpu
 
    interface recursion_gpu
@@ -130,6 +137,28 @@ contains
       call check(rc, 'rsrec_set_hamiltonian')
    end subroutine sync_device
 
+   !> local_axis runs: the library takes the GLOBAL-frame blocks (hamiltonian%*_glob) once; lsham is frame-independent input.
+   subroutine sync_device_global_frame(this)
+      class(recursion_gpu), intent(inout), target :: this
+      integer(c_int) :: rc, hoh_i
+      type(c_ptr) :: p_hall, p_hallo, p_eeo, p_enim
+      call sync_device(this, .true.)                             ! context + lattice tables (the blocks sent here are replaced below)
+      hoh_i = 0
+      p_eeo = c_null_ptr; p_enim = c_null_ptr; p_hall = c_null_ptr; p_hallo = c_null_ptr
+      if (this%hamiltonian%hoh) then
+         hoh_i = 1
+         p_eeo = c_loc(this%hamiltonian%eeo_glob)
+         p_enim = c_loc(this%hamiltonian%enim_glob)
+      end if
+      if (this%lattice%nmax > 0) then
+         p_hall = c_loc(this%hamiltonian%hall_glob)
+         if (this%hamiltonian%hoh) p_hallo = c_loc(this%hamiltonian%hallo_glob)
+      end if
+      rc = rsrec_set_hamiltonian(g_handle, int(size(this%hamiltonian%ee_glob, 3), c_int), hoh_i, int(this%control%nsp, c_int), &
+                                 c_loc(this%hamiltonian%ee_glob), c_loc(this%hamiltonian%lsham), p_eeo, p_enim, p_hall, p_hallo)
+      call check(rc, 'rsrec_set_hamiltonian')
+   end subroutine sync_device_global_frame
+
    !> Release the device context (optional; call once before MPI_FINALIZE).
    subroutine rsrec_gpu_shutdown()
       integer(c_int) :: rc
@@ -145,7 +174,8 @@ contains
       integer :: i, j, l, ll, llmax, nloc, i_loc
       integer(c_int) :: rc
       integer(c_int), allocatable, target :: seeds(:)
-      complex(rp), allocatable, target :: ab(:, :, :, :), bb(:, :, :, :)
+      complex(rp), allocatable, target :: ab(:, :, :, :), bb(:, :, :, :), rot(:, :, :)
+      real(rp) :: mom(3), sv(3)
 
       call get_mpi_variables(rank, this%lattice%nrec)            ! recursion.f90:1816
       llmax = this%lattice%control%lld
@@ -154,18 +184,28 @@ contains
       allocate (seeds(nloc), ab(18, 18, llmax, nloc), bb(18, 18, llmax, nloc))
 
       if (this%hamiltonian%local_axis) then
-         ! the reference re-rotates every Hamiltonian block into the spin frame of each site before its chain
-         ! (recursion.f90:1830-1832): H is per site, so sites are sent one at a time
+         ! The reference re-rotates every block into the spin frame of each site before its chain (recursion.f90:1830-1832), i.e.
+         ! H is per site.  All sites still go in ONE call: the library gets the GLOBAL-frame blocks (the *_glob arrays
+         ! rotate_to_local_axis starts from, hamiltonian.f90:2451-2461) plus one rotation matrix per site, runs every chain on the
+         ! global blocks with that site's on-site term R l.s R^H and conjugates the 18x18 outputs (see include/rsrec.h).
+         allocate (rot(18, 18, nloc))
          do i = start_atom, end_atom
             i_loc = i - start_atom + 1
             j = this%lattice%irec(i)
             call g_logger%info('Block recursion on progress for atom '//int2str(j), __FILE__, __LINE__)
-            call this%hamiltonian%rotate_to_local_axis(this%lattice%symbolic_atoms(i)%potential%mom)
-            call sync_device(this, i == start_atom)
-            seeds(1) = int(j, c_int)
-            rc = rsrec_block_lanczos(g_handle, 1_c_int, c_loc(seeds), int(llmax, c_int), c_loc(ab(1, 1, 1, i_loc)), c_loc(bb(1, 1, 1, i_loc)))
-            call check(rc, 'rsrec_block_lanczos')
+            seeds(i_loc) = int(j, c_int)
+            mom = this%lattice%symbolic_atoms(i)%potential%mom
+            call car2sph(mom, sv)                                 ! rotmag_loc, math.f90:2021-2026
+            rot(:, :, i_loc) = (0.0_rp, 0.0_rp)
+            call ROTMAT(rot(:, :, i_loc), sv(1), sv(2), 0.0_rp)
          end do
+         call sync_device_global_frame(this)
+         call g_timer%start('H|PSI_n>')
+         rc = rsrec_block_lanczos_local_axis(g_handle, int(nloc, c_int), c_loc(seeds), c_loc(rot), int(llmax, c_int), c_loc(ab), c_loc(bb))
+         call g_timer%stop('H|PSI_n>')
+         call check(rc, 'rsrec_block_lanczos_local_axis')
+         ! leave the Hamiltonian object as the reference's loop does: rotated into the frame of the last site
+         call this%hamiltonian%rotate_to_local_axis(this%lattice%symbolic_atoms(end_atom)%potential%mom)
       else
          call sync_device(this, .true.)
          do i = start_atom, end_atom
@@ -373,5 +413,165 @@ contains
       this%a(1:this%lattice%control%lld, :, 1:nloc, 1) = a(1:this%lattice%control%lld, :, :)
       this%b2(1:this%lattice%control%lld, :, 1:nloc, 1) = b2(1:this%lattice%control%lld, :, :)
    end subroutine gpu_recur
+
+   !---------------------------------------------------------------------------
+   !> Band-dependent terminator (replaces recursion.f90:2092-2135 with get_cinf :2030, bpopt :3540, emami :3589): all `na` sites and
+   !> all 324 matrix elements in one kernel launch
+   !---------------------------------------------------------------------------
+   subroutine gpu_get_terminf(this, Acoef_b, B2coef_b, na, ll, ldim, nw, a_inf, b_inf, a_inf0, b_inf0)
+      class(recursion_gpu), intent(inout) :: this
+      integer, intent(in) :: na
+      integer, intent(in) :: ll
+      integer, intent(inout) :: nw
+      integer, intent(in) :: ldim
+      complex(rp), dimension(ldim, ldim, ll, na), intent(in) :: Acoef_b, B2coef_b
+      real(rp), dimension(ldim, ldim, na), intent(out) :: a_inf, b_inf
+      real(rp), dimension(na), intent(out) ::  a_inf0, b_inf0
+      integer(c_int) :: rc
+      complex(rp), allocatable, target :: ac(:, :, :, :), bc(:, :, :, :)
+      real(rp), allocatable, target :: ai(:, :, :), bi(:, :, :), a0(:), b0(:)
+      type(c_ptr) :: h
+
+      if (ldim /= 18) call g_logger%fatal('recursion_gpu%get_terminf: ldim must be 18', __FILE__, __LINE__)
+      if (na <= 0) return
+      h = rsrec_gpu_context()
+      allocate (ac(18, 18, ll, na), bc(18, 18, ll, na), ai(18, 18, na), bi(18, 18, na), a0(na), b0(na))
+      ac = Acoef_b; bc = B2coef_b
+      rc = rsrec_terminator(h, int(na, c_int), int(ll, c_int), c_loc(ac), c_loc(bc), c_loc(ai), c_loc(bi), c_loc(a0), c_loc(b0))
+      call check(rc, 'rsrec_terminator')
+      a_inf = ai; b_inf = bi; a_inf0 = a0; b_inf0 = b0
+   end subroutine gpu_get_terminf
+
+   !---------------------------------------------------------------------------
+   !> Stochastic Kubo-Bastin double moments (replaces recursion.f90:979-1234).  Operator set-up (setup_kubo_operators :242) and the
+   !> seeds stay the reference's: per_type -> identity on lattice%atlist(i); random_vec -> the reference's random_seed / random_number
+   !> sequence, one phase per atom (:1103-1114).  Everything after that -- 3 cond_ll block SpMMs and the cond_ll^2 moment contraction
+   !> per vector -- runs in one library call.
+   !---------------------------------------------------------------------------
+   subroutine gpu_compute_moments_stochastic(this)
+      use math_mod, only: pi, i_unit
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, k, loop_over, nseed, cll
+      integer(c_int) :: rc
+      real(rp) :: a, b, rng
+      integer(c_int), allocatable, target :: seeds(:, :)
+      complex(rp), allocatable, target :: coef(:, :), mu(:, :, :, :, :), va(:, :, :, :), vb(:, :, :, :), voa(:, :, :, :), vob(:, :, :, :)
+      type(c_ptr) :: p_voa, p_vob
+
+      cll = this%control%cond_ll
+      select case (this%control%cond_calctype)
+      case ('per_type')
+         loop_over = this%lattice%ntype
+         nseed = 1
+      case ('random_vec')
+         loop_over = this%control%random_vec_num
+         nseed = this%lattice%kk
+      case default
+         call g_logger%fatal('recursion_gpu%compute_moments_stochastic: unknown cond_calctype', __FILE__, __LINE__)
+         return
+      end select
+      if (allocated(this%mu_nm_stochastic)) deallocate (this%mu_nm_stochastic)
+      allocate (this%mu_nm_stochastic(18, 18, cll, cll, loop_over))
+      a = (this%en%energy_max - this%en%energy_min)/(2 - 0.3)      ! :1023-1024
+      b = (this%en%energy_max + this%en%energy_min)/2
+      call this%setup_kubo_operators(this%control%linear_out, this%control%linear_in)
+      allocate (seeds(nseed, loop_over), coef(nseed, loop_over))
+      do i = 1, loop_over
+         call random_seed()                                       ! :1076
+         if (nseed == 1) then
+            seeds(1, i) = int(this%lattice%atlist(i), c_int)
+            coef(1, i) = (1.0_rp, 0.0_rp)
+         else
+            do k = 1, this%lattice%kk
+               call random_number(rng)
+               seeds(k, i) = int(k, c_int)
+               coef(k, i) = exp(2.0_rp*pi*i_unit*rng)/sqrt(real(this%lattice%kk))
+            end do
+         end if
+      end do
+      call sync_device(this, .true.)
+      p_voa = c_null_ptr; p_vob = c_null_ptr
+      allocate (va, source=this%hamiltonian%v_a)
+      allocate (vb, source=this%hamiltonian%v_b)
+      if (this%hamiltonian%hoh) then
+         allocate (voa, source=this%hamiltonian%vo_a)
+         allocate (vob, source=this%hamiltonian%vo_b)
+         p_voa = c_loc(voa)
+         p_vob = c_loc(vob)
+      end if
+      allocate (mu(18, 18, cll, cll, loop_over))
+      rc = rsrec_kubo_moments(g_handle, int(loop_over, c_int), int(nseed, c_int), c_loc(seeds), c_loc(coef), int(cll, c_int), &
+                              real(a, c_double), real(b, c_double), c_loc(va), p_voa, c_loc(vb), p_vob, c_loc(mu))
+      call check(rc, 'rsrec_kubo_moments')
+      this%mu_nm_stochastic = mu
+   end subroutine gpu_compute_moments_stochastic
+
+   !---------------------------------------------------------------------------
+   !> Whole-vector products on caller arrays (replace recursion.f90:913, :785, :587, :656).  With these overridden, the inherited
+   !> chebyshev_orbital_mod (:2834) runs its H|psi> on the GPU.  The region flags are left "all active" for the caller's
+   !> `izero = idum` bookkeeping (blocks outside the reference's region are exact zeros).
+   !---------------------------------------------------------------------------
+   subroutine gpu_apply(this, vel, v_op, vo_op, psi_in, psi_out, a, b)
+      class(recursion_gpu), intent(inout), target :: this
+      integer, intent(in) :: vel
+      complex(rp), dimension(:, :, :, :), intent(in), target, optional :: v_op, vo_op
+      complex(rp), dimension(:, :, :), intent(in) :: psi_in
+      complex(rp), dimension(:, :, :), intent(out) :: psi_out
+      real(rp), intent(in) :: a, b
+      integer(c_int) :: rc
+      complex(rp), allocatable, target :: xin(:, :, :), xout(:, :, :), v(:, :, :, :), vo(:, :, :, :)
+      type(c_ptr) :: pv, pvo
+      call sync_device(this, .true.)
+      allocate (xin(18, 18, this%lattice%kk), xout(18, 18, this%lattice%kk))
+      xin = psi_in(:, :, 1:this%lattice%kk)
+      pv = c_null_ptr; pvo = c_null_ptr
+      if (present(v_op)) then
+         allocate (v, source=v_op)
+         pv = c_loc(v)
+      end if
+      if (present(vo_op)) then
+         allocate (vo, source=vo_op)
+         pvo = c_loc(vo)
+      end if
+      rc = rsrec_apply_operator(g_handle, int(vel, c_int), pv, pvo, c_loc(xin), c_loc(xout), real(a, c_double), real(b, c_double))
+      call check(rc, 'rsrec_apply_operator')
+      psi_out(:, :, 1:this%lattice%kk) = xout
+      this%idum(:) = 1
+   end subroutine gpu_apply
+
+   subroutine gpu_ham_vec_matmul(this, psi_in, psi_out, a, b)
+      class(recursion_gpu), intent(inout) :: this
+      complex(rp), dimension(:, :, :), intent(in) :: psi_in
+      complex(rp), dimension(:, :, :), intent(out) :: psi_out
+      real(rp), intent(in) :: a, b
+      call gpu_apply(this, 0, psi_in=psi_in, psi_out=psi_out, a=a, b=b)
+   end subroutine gpu_ham_vec_matmul
+
+   subroutine gpu_ham_hoh_vec_matmul(this, psi_in, psi_out, a, b)
+      class(recursion_gpu), intent(inout) :: this
+      complex(rp), dimension(:, :, :), intent(in) :: psi_in
+      complex(rp), dimension(:, :, :), intent(out) :: psi_out
+      real(rp), intent(in) :: a, b
+      call gpu_apply(this, 0, psi_in=psi_in, psi_out=psi_out, a=a, b=b)     ! the library applies the operator that was set (hoh or not)
+   end subroutine gpu_ham_hoh_vec_matmul
+
+   subroutine gpu_velo_vec_matmul(this, c_or_n, v_op, psi_in, psi_out)
+      class(recursion_gpu), intent(inout) :: this
+      complex(rp), dimension(:, :, :, :), intent(in) :: v_op
+      complex(rp), dimension(:, :, :), intent(in) :: psi_in
+      character :: c_or_n
+      complex(rp), dimension(:, :, :), intent(out) :: psi_out
+      if (c_or_n /= 'n' .and. c_or_n /= 'N') call g_logger%fatal("recursion_gpu%velo_vec_matmul: only 'n' (every call site of the reference)", __FILE__, __LINE__)
+      call gpu_apply(this, 1, v_op=v_op, psi_in=psi_in, psi_out=psi_out, a=1.0_rp, b=0.0_rp)
+   end subroutine gpu_velo_vec_matmul
+
+   subroutine gpu_velo_hoh_vec_matmul(this, v_op, vo_op, psi_in, psi_out)
+      class(recursion_gpu), intent(inout) :: this
+      complex(rp), dimension(:, :, :), intent(in) :: psi_in
+      complex(rp), dimension(:, :, :), intent(out) :: psi_out
+      complex(rp), dimension(:, :, :, :), intent(in) :: v_op
+      complex(rp), dimension(:, :, :, :), intent(in) :: vo_op
+      call gpu_apply(this, 1, v_op=v_op, vo_op=vo_op, psi_in=psi_in, psi_out=psi_out, a=1.0_rp, b=0.0_rp)
+   end subroutine gpu_velo_hoh_vec_matmul
 
 end module recursion_gpu_mod

@@ -98,6 +98,60 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_block_lanczos_local_axis(handle, nsites, seed_atoms, rot, lld, a_b, b2_b) &
+         bind(C, name='rsrec_block_lanczos_local_axis') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld
+         type(c_ptr), value :: seed_atoms, rot, a_b, b2_b
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_pack_diag(handle, site_offset, nsites_total, a_img, b2_img) bind(C, name='rsrec_pack_diag') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: site_offset, nsites_total
+         type(c_ptr), value :: a_img, b2_img
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_terminator(handle, nsites, lld, a_b, b_sqrt, a_inf, b_inf, a_inf0, b_inf0) bind(C, name='rsrec_terminator') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, lld
+         type(c_ptr), value :: a_b, b_sqrt, a_inf, b_inf, a_inf0, b_inf0
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_block_ldos(handle, nen, ene, eta_re, eta_im, sym_term, site_offset, nsites_total, dtot, dosia, dosial, a_inf, b_inf) &
+         bind(C, name='rsrec_block_ldos') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nen, sym_term, site_offset, nsites_total
+         real(c_double), value :: eta_re, eta_im
+         type(c_ptr), value :: ene, dtot, dosia, dosial, a_inf, b_inf
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_kubo_moments(handle, nvec, nseed, seed_atoms, seed_coef, cond_ll, a, b, v_a, vo_a, v_b, vo_b, mu_nm) &
+         bind(C, name='rsrec_kubo_moments') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nvec, nseed, cond_ll
+         real(c_double), value :: a, b
+         type(c_ptr), value :: seed_atoms, seed_coef, v_a, vo_a, v_b, vo_b, mu_nm
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_apply_operator(handle, vel, v_op, vo_op, psi_in, psi_out, a, b) bind(C, name='rsrec_apply_operator') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: vel
+         real(c_double), value :: a, b
+         type(c_ptr), value :: v_op, vo_op, psi_in, psi_out
+         integer(c_int) :: rc
+      end function
+
       function rsrec_zsqr(handle, nmat, b2_b) bind(C, name='rsrec_zsqr') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

@@ -106,6 +106,101 @@ def generated_cases():
                      "source": "generated: oracle/_ref/rslmto_ref.x (the compiled reference) run by oracle/make_scf_fixtures.py on tests/scf/cases/bulk/bccFe with mom = (0.6, 0, 0.8), local_axis = T"}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+    out.update(generated_local_axis_multisite(exe))
+    out.update(generated_conductivity(exe))
+    return out
+
+
+def _run_reference(exe, dst, patch, timeout=3000):
+    """Run the compiled reference in a scratch copy of `dst` (the committed input files) with `patch` applied; returns the work dir."""
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from oracle.make_fixtures import patch_namelist
+    work = tempfile.mkdtemp(prefix="rsrec_scf_gen_")
+    for fn in os.listdir(dst):
+        shutil.copy(os.path.join(dst, fn), os.path.join(work, fn))
+    p = os.path.join(work, "input.nml")
+    txt = patch_namelist(open(p).read(), patch)
+    open(p, "w").write(txt)
+    env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
+    r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=work, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    return work
+
+
+def _nml_val(txt, key, idx=0):
+    m = re.search(r"(?im)^\s*%s\s*=\s*(.+)$" % key, txt)
+    return [float(v.replace("D", "E").replace("d", "e")) for v in re.findall(r"[-+]?[0-9]*\.?[0-9]+(?:[eEdD][-+]?[0-9]+)?", m.group(1))][idx]
+
+
+def generated_local_axis_multisite(exe):
+    """Generated_bulk_Pt2MnGa_nsp4_local_axis: four recursion sites (Mn, Ga, Pt1, Pt2) whose moments point along four different
+    axes, hamiltonian%local_axis = T: every site's chain runs in its own spin frame (recursion.f90:1830-1832).  Exercises the batched
+    local-axis call and the all-sites terminator of the drop-in."""
+    name = "Generated_bulk_Pt2MnGa_nsp4_local_axis"
+    dst = os.path.join(OUT, "inputs", "bulk_Pt2MnGa_tilted")
+    os.makedirs(dst, exist_ok=True)
+    src = os.path.join(REF, "tests/scf/cases/bulk/Pt2MnGa")
+    moms = {"Mn.nml": (0.6, 0.0, 0.8), "Ga.nml": (0.0, 0.0, 1.0), "Pt1.nml": (0.0, 0.8, 0.6), "Pt2.nml": (-0.36, 0.48, 0.8)}
+    for fn in os.listdir(src):
+        if fn.endswith(".nml"):
+            t = open(os.path.join(src, fn)).read()
+            if fn in moms:
+                t = re.sub(r"(?im)^(\s*mom\s*=\s*)[^\n]*", lambda mm: mm.group(1) + "%.16g, %.16g, %.16g" % moms[fn], t, count=1)
+            open(os.path.join(dst, fn), "w").write(t)
+            os.chmod(os.path.join(dst, fn), 0o644)
+    patch = {"control": {"nsp": "4", "recur": "'block'", "lld": "20"}, "self": {"nstep": "1"}, "hamiltonian": {"hoh": ".false.", "local_axis": ".true."}}
+    work = _run_reference(exe, dst, patch)
+    try:
+        exp = {}
+        for lab in ("Mn", "Ga", "Pt1", "Pt2"):
+            txt = open(os.path.join(work, lab + "_out.nml")).read()
+            exp[lab + "_out.nml"] = {"etot": _nml_val(txt, "etot"), "ws_r": _nml_val(txt, "ws_r")}
+        rows = open(os.path.join(work, "totaldos.out")).read().splitlines()
+        text = {str(rw): {"1": float(rows[rw - 1].split()[0]), "2": float(rows[rw - 1].split()[1])} for rw in (500, 1000, 1500)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return {name: {"inputs": os.path.relpath(dst, OUT), "patch": patch, "expected": {"nml": exp, "text": {"totaldos.out": text}}, "abs_tol": 1e-6, "rel_tol": 1e-6,
+                   "source": "generated: oracle/_ref/rslmto_ref.x (the compiled reference) run by oracle/make_scf_fixtures.py on tests/scf/cases/bulk/Pt2MnGa with four "
+                             "different moment directions (%s), nsp = 4, local_axis = T" % moms}}
+
+
+def generated_conductivity(exe):
+    """Generated_conductivity_fccPt_spin[_hoh]: the reference's conductivity post-processing (calculation.f90:960-1078) on its
+    tests/postproc fcc Pt case, spin-Hall response (linear_out = 'spin', linear_in = 'charge').  The committed ref.json of that case
+    cannot be reproduced by the reference's own source any more: the case file carries two keys the namelists no longer declare
+    (js_alpha, cond_type), the read of those groups aborts with a logged error, and the run falls back to the charge-charge response
+    (zero by symmetry, 1e-13).  The stale keys are removed here and the response is named explicitly; expected values come from the
+    compiled reference."""
+    out = {}
+    src = os.path.join(REF, "tests/postproc/cases/conductivity/fccPt")
+    dst = os.path.join(OUT, "inputs", "conductivity_fccPt")
+    os.makedirs(dst, exist_ok=True)
+    txt = open(os.path.join(src, "input.nml")).read()
+    txt = "\n".join(l for l in txt.splitlines() if not re.match(r"\s*(js_alpha|cond_type)\s*=", l)) + "\n"
+    head, sep, tail = txt.rpartition("&hamiltonian")           # second &hamiltonian group (hoh only): a namelist read takes the first
+    if "&hamiltonian" in head:
+        txt = head + tail[tail.index("/") + 1:]
+    open(os.path.join(dst, "input.nml"), "w").write(txt)
+    shutil.copy(os.path.join(src, "Pt.nml"), os.path.join(dst, "Pt.nml"))
+    for fn in ("input.nml", "Pt.nml"):
+        os.chmod(os.path.join(dst, fn), 0o644)
+    for hoh in (False, True):
+        name = "Generated_conductivity_fccPt_spin" + ("_hoh" if hoh else "")
+        patch = {"control": {"nsp": "2", "recur": "'chebyshev'", "lld": "50", "linear_out": "'spin'", "linear_in": "'charge'"}, "self": {"nstep": "1"},
+                 "hamiltonian": {"hoh": ".true." if hoh else ".false."}}
+        work = _run_reference(exe, dst, patch)
+        try:
+            rows = open(os.path.join(work, "Pt_cond.out")).read().splitlines()
+            text = {str(rw): {str(c + 1): float(rows[rw - 1].split()[c]) for c in range(3)} for rw in (500, 1000, 1500)}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+        out[name] = {"inputs": os.path.relpath(dst, OUT), "patch": patch, "expected": {"text": {"Pt_cond.out": text}}, "abs_tol": 1e-6, "rel_tol": 1e-6,
+                     "exe": "kubo_gpu.x",
+                     "source": "generated: oracle/_ref/rslmto_ref.x (the compiled reference, post_processing = 'conductivity') run by oracle/make_scf_fixtures.py on "
+                               "tests/postproc/cases/conductivity/fccPt (stale keys js_alpha / cond_type removed, spin-Hall response named explicitly)"}
     return out
 
 
