@@ -55,7 +55,6 @@ def parse_args():
     ap.add_argument("--spin-mixing", action="store_true", help="stencil rotated into a tilted spin frame: spin-flip entries in every block")
     ap.add_argument("--kernels", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--spmm4", type=int, default=-1, help="small-launch SpMM kernel selection (library option); -1 = library default")
     ap.add_argument("--no-positions", action="store_true", help="do not pass atom positions (locality hint)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development sweeps), may be repeated")
     ap.add_argument("--no-cpu", action="store_true")
@@ -286,8 +285,6 @@ def main():
         rec.set_option("kernels", args.kernels)
     if args.batch:
         rec.set_option("batch", args.batch)
-    if args.spmm4 >= 0:
-        rec.set_option("spmm4", args.spmm4)
     for kv in args.opt:
         k, v = kv.split("=")
         rec.set_option(k, int(v))
@@ -352,7 +349,7 @@ def main():
     if rank == 0:
         variant = ("hoh " if args.hoh else "") + ("spin-mixing " if args.spin_mixing else "")
         wl_key = "%s%s%s_c%d_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", "_mix" if args.spin_mixing else "", n, args.sites, args.lld)
-        tuned = bool(args.kernels or args.batch or args.spmm4 >= 0 or args.no_positions or args.opt)
+        tuned = bool(args.kernels or args.batch or args.no_positions or args.opt)
         # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + POST_FLOP_BLOCKS[args.recur] * tm_acc["atom_steps"])
         flop_total = flop_rank * world

@@ -67,6 +67,8 @@ program kubo_gpu_driver
    call recursion_obj%compute_moments_stochastic()
    call system_clock(t1)
    write (*, '(a,f12.6,a)') 'kubo_gpu_driver: compute_moments_stochastic wall time ', real(t1 - t0)/real(rate), ' s'
+   write (*, '(a,es14.6,a,es14.6)') 'kubo_gpu_driver: max |mu_nm| = ', maxval(abs(recursion_obj%mu_nm_stochastic)), '  max |mu(:,:,1,1)| = ', &
+      maxval(abs(recursion_obj%mu_nm_stochastic(:, :, 1, 1, :)))
    dos_obj = dos(recursion_obj, energy_obj)
    green_obj = green(dos_obj)
    bands_obj = bands(green_obj)

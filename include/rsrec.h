@@ -203,14 +203,12 @@ int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
 /* ---- tuning / measurement (not part of the reference interface) ---- */
 /* key/value knobs (defaults in brackets; everything but "batch" and "kernels" exists for A/B measurements and tests):
  *   "batch"      chains advanced together per launch [0 = auto: up to 64, bounded by free device memory]
- *   "kernels"    0 = auto, 1 = FP64 VALU kernel set (reference layout), 2 = matrix-core kernel set [0]
- *   "three_term" block Lanczos formulation: 0 = the reference's literal order, 1 = normalised three-term, 2 = un-normalised (u-scheme) [2]
- *   "spmm4"      small-launch SpMM: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative [-1]
- *   "spmm5"      large-launch SpMM k_spmm5: 0 off, 1 auto (>= 4096 groups per launch; always for hoh), 2 always [1]
+ *   "kernels"    0 = auto, 1 = FP64 VALU kernel set (the reference's layout and operation order; any stencil), 2 = matrix-core set [0]
+ *   "spmm5"      SpMM of the matrix-core set: 0 = small-launch kernel k_spmm4<4> (LayoutRM vectors), 1 = by launch size (k_spmm5 on CI
+ *                vectors from 4096 groups per launch; always for hoh and local-axis runs), 2 = always k_spmm5 [1]
  *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u> [1]
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
- *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none]
- *   "post", "fuse", "wps"  older pipeline variants kept for cross-checks [0, 0, 1] */
+ *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
 /* Timing of the last recursion call, measured with HIP events on the engine's own stream:
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,

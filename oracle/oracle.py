@@ -155,6 +155,21 @@ def block_green(a_b, b_sqrt, ene, a_inf, b_inf, eta=0.0 + 0.0j, sym_term=False):
     return g0
 
 
+def terminator(a_b, b_sqrt):
+    """recursion%get_terminf (recursion.f90:2092): a_b, b_sqrt (18,18,lld,nsites) -> a_inf, b_inf (18,18,nsites), a_inf0, b_inf0 (nsites)."""
+    a_b = np.asfortranarray(a_b, dtype=np.complex128); b_sqrt = np.asfortranarray(b_sqrt, dtype=np.complex128)
+    lld, n = a_b.shape[2], a_b.shape[3]
+    a_inf = np.zeros((18, 18, n), order="F"); b_inf = np.zeros_like(a_inf)
+    a0, b0 = np.zeros(n), np.zeros(n)
+    L = lib()
+    L.orc_terminator.restype = C.c_int
+    L.orc_terminator.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
+    rc = L.orc_terminator(n, lld, a_b.ctypes.data_as(C.c_void_p), b_sqrt.ctypes.data_as(C.c_void_p), a_inf.ctypes.data_as(C.c_void_p),
+                          b_inf.ctypes.data_as(C.c_void_p), a0.ctypes.data_as(C.c_void_p), b0.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return a_inf, b_inf, a0, b0
+
+
 def chebyshev_green(mu_n, ene, emin, emax):
     """green%chebyshev_green (green.f90:1030) for ONE site: mu_n (18,18,2lld+2) -> g0 (18,18,len(ene))."""
     mu_n = np.asfortranarray(mu_n, dtype=np.complex128)

@@ -78,7 +78,6 @@ struct rsrec_handle {
     // hamiltonian
     int hslots = 0, hoh = 0, nsp = 2;
     DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
-    MfmaOperator mfma_op;
     Spmm4Operator s4_op;
     int s4_built_split = 0;
     Spmm5Operator s5_op;
@@ -95,7 +94,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_wps = 1, opt_post = 0, opt_three = 2, opt_spmm4 = -1, opt_fuse = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;   // spmm4: -1 auto, 0 = 16x16x4 kernel, 1 = 4x4x4 one wave per group, 4 = 4x4x4 cooperative   // fuse: A_n inside the SpMM kernel (correct, but its epilogue is not overlapped at 1 wave/SIMD: slower for now)
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -321,7 +320,6 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
-    h->mfma_op.release();
     h->s4_op.release();
     h->s5_op.release();
     h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release(); h->s5_la.release(); h->d_la_extra.release();
@@ -348,15 +346,10 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     if (!strcmp(key, "batch")) h->opt_batch = value;
     else if (!strcmp(key, "kernels")) h->opt_kernels = value;
     else if (!strcmp(key, "nblk")) h->opt_nblk = value;
-    else if (!strcmp(key, "wps")) h->opt_wps = value;
-    else if (!strcmp(key, "post")) h->opt_post = value;
-    else if (!strcmp(key, "fuse")) h->opt_fuse = value;
-    else if (!strcmp(key, "three_term")) h->opt_three = value;
     else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
-    else if (!strcmp(key, "spmm4")) h->opt_spmm4 = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -513,9 +506,8 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
     }
     // MFMA-fragment form of the same operator tables
     {
-        const char* msg = h->mfma_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
-                                           (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham);
-        if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
+        const char* msg = nullptr;
+        h->s4_built_split = 0; h->s5_built = 0;
         if (h->nslots + 1 <= S4_MAXSLOTS) {
             const int nsplit = 1;
             msg = h->s4_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
@@ -772,30 +764,19 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
     return out;
 }
 
-// store-mode SpMM dispatch: out = sum_slots H_slot in_nbr for operator set `set` (0 = h, 1 = h*o)
+// k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
+bool spmm4_usable(const rsrec_t* h) { return h->s4_built_split && (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32); }
+
+// small-launch SpMM on LayoutRM vectors: out = sum_slots H_slot in_nbr, four waves share one group of atoms (k_spmm4<4>)
 int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
-    // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
-    const bool s4_addressable = (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32);
-    if (h->opt_spmm4 != 0 && h->s4_built_split && s4_addressable) {
-        // auto: cooperative (4 waves per group) when there are too few groups to give every wave its own -- it also has the
-        // lowest fabric traffic; one wave per group when the launch is large (its per-group overheads amortise better)
-        const long groups_max = (long)grid_mf.y * (h->kk / GROUP + 1);
-        const bool coop = h->opt_spmm4 == 4 || (h->opt_spmm4 < 0 && groups_max < 4096);
-        if (coop) {
-            static bool attr = false;
-            if (!attr) {
-                HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS_BYTES));
-                attr = true;
-            }
-            // one group per workgroup at a time: 4x as many workgroups keep the same number of groups in flight per launch
-            dim3 g4(std::min<unsigned>(grid_mf.x * 4, 1024), grid_mf.y);
-            k_spmm4<4><<<g4, MF_WAVES * 64, S4_LDS_BYTES, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
-        } else {
-            k_spmm4<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
-        }
-    } else {
-        k_mfma_spmm<1, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->mfma_op.set_ptr(set), in, out, nullptr);
+    static bool attr = false;
+    if (!attr) {
+        HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS_BYTES));
+        attr = true;
     }
+    // one group per workgroup at a time: 4x as many workgroups keep the same number of groups in flight per launch
+    dim3 g4(std::min<unsigned>(grid_mf.x * 4, 1024), grid_mf.y);
+    k_spmm4<4><<<g4, MF_WAVES * 64, S4_LDS_BYTES, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
     return RSREC_OK;
 }
 
@@ -809,17 +790,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
     int nvec = MFMA ? 4 : (hoh ? 3 : 2);
-    const bool three_term = MFMA && !hoh && h->opt_post != 1 && !h->opt_fuse && h->opt_three;
-    const bool u_scheme = three_term && h->opt_three == 2 && h->opt_wps != 2;
-    // large launches: k_spmm5 with every vector in the CI layout; small launches keep the cooperative k_spmm4<4> on LayoutRM
-    // (spmm5 = 2 forces k_spmm5)
-    const bool use_kp = u_scheme && h->s5_built && h->opt_spmm4 != 0 &&
-                        (rot || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && h->opt_spmm4 < 0 && (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096));
-    // hoh on the un-normalised scheme: both SpMM passes in k_spmm5 (first pass writes KP, second pass adds the on-site
-    // e_nu + l.s term from psi through its extra slot), then the same post-hop kernels as without hoh
-    const bool u_hoh = MFMA && hoh && h->opt_post != 1 && h->opt_three == 2 && h->opt_wps != 2 && h->s5_built && h->opt_spmm5 >= 1 && h->opt_spmm4 != 0;
-    const int ci = (use_kp || u_hoh) ? 1 : 0;                 // vectors of this call are CI (else LayoutRM / LayoutCM)
-    if (rot && !(MFMA && ci)) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set with k_spmm5 (options kernels / spmm5 / three_term at their defaults)");
+    // Matrix-core set: large launches, hoh and local-axis runs use k_spmm5 with every vector in the CI layout; small launches of the
+    // plain operator keep the cooperative k_spmm4<4> on LayoutRM (option spmm5: 0 = never, 1 = by launch size, 2 = always)
+    const bool large = (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096;
+    const int ci = (MFMA && (hoh || rot || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && large) || !spmm4_usable(h))) ? 1 : 0;   // vectors of this call are CI (else LayoutRM / LayoutCM)
+    if (rot && !MFMA) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set (option kernels = 0 or 2)");
     const int ntau = h->nmax + h->ntype;
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
     if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * S5_FRAG_PER_SLOT * sizeof(double)));
@@ -837,7 +812,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         HIPCK(h, hipEventCreateWithFlags(&h->ev_orth, hipEventDisableTiming));
         HIPCK(h, hipEventCreateWithFlags(&h->ev_bred, hipEventDisableTiming));
     }
-    HIPCK(h, h->d_frags.reserve((size_t)B * 4 * 27 * 64 * sizeof(double)));
+    HIPCK(h, h->d_frags.reserve((size_t)B * 3 * 27 * 64 * sizeof(double)));
     // the coefficients of ALL chains of the call stay on the device (resident input of rsrec_pack_diag / rsrec_block_ldos)
     h->res_kind = 0;
     HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
@@ -854,16 +829,14 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     double2* partial = h->d_partial.as<double2>();
     double* gpartial = h->d_partial.as<double>();
     double* gpartial_b = gpartial + gram_elems;          // Gram partials of k_mfma_orth3 when their reduction runs on the side stream
-    double* afrags = h->d_frags.as<double>();
-    double* bfrags = afrags + (size_t)B * 27 * 64;
-    const bool mf_post = MFMA && h->opt_post != 1;
+    double* bfrags = h->d_frags.as<double>();            // [chain][3][27 * 64]: the three right-multiply tables of k_mfma_orth3
     const DevProblem P = make_problem(h);
     HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_orth<L>), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ATOMS * BLK * (int)sizeof(double2)));
     const size_t cstride = (size_t)lld * BLK;
     const size_t orth_lds = TILE_ATOMS * BLK * sizeof(double2);
     hipEvent_t ev_begin = next_event(h);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
-    h->hop_fuses_a = (MFMA && (hoh || !(h->opt_post != 1 && h->opt_fuse))) ? 0 : 1;
+    h->hop_fuses_a = MFMA ? 0 : 1;
 
     for (int c0 = 0; c0 < nchains; c0 += B) {
         const int nb = std::min(B, nchains - c0);
@@ -925,11 +898,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
         if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
-        psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (the three-term scheme swaps them every level)
+        psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (swapped every level)
         if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         else k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
         k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
-        if (u_scheme || u_hoh) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags, ci);
+        if (MFMA) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags, ci);
         const dim3 grid(nblk, nb);
         const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
         // u-scheme: H u_{n+1} does not need B_{n+1}, so the reduction of sum u_{n+1}^H u_{n+1} and its 18x18 eigen-solve (one
@@ -962,78 +935,22 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             hipEvent_t e1 = nullptr;
             ApplyArgs G{};
             G.partial = partial;
-            if (!hoh) {
-                if (MFMA) {
-                    const SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase, nb};
-                    const double* frag = h->mfma_op.set_ptr(0);
-                    if (mf_post && h->opt_fuse) {
-                        // fused hop_b: pmn <- H psi - pmn and the A_n partial inside the SpMM kernel
-                        if (h->opt_wps == 2) k_mfma_spmm<2, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, pmn, gpartial);
-                        else k_mfma_spmm<1, true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, pmn, gpartial);
-                        e1 = next_event(h);
-                        k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
-                        k_mfma_orth<0><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
-                        k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                       h->d_status.as<int>());
-                        k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
-                        hop_ev.emplace_back(e0, e1);
-                        h->n_hop_launch += 1;
-                        continue;
-                    }
-                    if (h->opt_wps == 2) k_mfma_spmm<2, false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, frag, psi, hpsi, nullptr);
-                    else if (use_kp && rot) k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi, psi, la_extra, ntau);
-                    else if (use_kp) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), psi, hpsi);
+            if (MFMA) {
+                // matrix-core kernel set, un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
+                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * ll + 1 : lv_final, velems, CV.obase, nb};
+                if (!hoh) {
+                    if (ci && rot) k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi, psi, la_extra, ntau);
+                    else if (ci) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
-                    e1 = next_event(h);
-                    tvec = hpsi;
-                    if (mf_post) {
-                        if (u_scheme) {
-                            // un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
-                            const dim3 gl = level_grid(h, grid_mf, lv_final);
-                            k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                            { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
-                              rc = wait_b_level(); if (rc) return rc;
-                              k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
-                            k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                            rc = reduce_b_level(gl.x, ll); if (rc) return rc;
-                            std::swap(psi, t2);
-                            hop_ev.emplace_back(e0, e1);
-                            h->n_hop_launch += 1;
-                            continue;
-                        }
-                        k_mfma_adot<<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                        k_reduce_a_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dA + (size_t)ll * BLK, cstride, afrags);
-                        if (three_term) {
-                            // psi = psi_n, t2 = psi_{n-1}: pmn <- t - psi_{n-1} B_n - psi_n A_n ; psi_{n+1} = pmn Binv overwrites the psi_{n-1} buffer
-                            k_mfma_orth<2><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial, t2, bfrags);
-                            k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                           h->d_status.as<int>());
-                            k_mfma_update<true><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, t2, pmn, bfrags);
-                            std::swap(psi, t2);
-                        } else {
-                            k_mfma_orth<1><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, hpsi, afrags, gpartial);
-                            k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                                           h->d_status.as<int>());
-                            k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
-                        }
-                        hop_ev.emplace_back(e0, e1);
-                        h->n_hop_launch += 1;
-                        continue;
-                    }
-                    k_adot<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, hpsi, partial);
                 } else {
-                    G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                    k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                    e1 = next_event(h);
+                    // H = h - (h o) h + e_nu + l.s in two passes of k_spmm5: h psi, then the rest with psi as second input (extra on-site slot)
+                    double* hps = pmn;                   // (the pmn buffer is free in the u-scheme)
+                    k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hps);
+                    SD.level = lv_final;
+                    k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(1), OP.meta_set(1), hps, hpsi, psi, la_extra, ntau);
                 }
-            } else if (u_hoh) {
-                double* hps = pmn;                       // the pmn buffer is free in the u-scheme: h psi of the first pass
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
-                const dim3 gl = level_grid(h, grid_mf, lv_final);
-                k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hps);
-                SD.level = lv_final;
-                k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(1), OP.meta_set(1), hps, hpsi, psi, la_extra, ntau);
                 e1 = next_event(h);
+                const dim3 gl = level_grid(h, grid_mf, lv_final);
                 k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
                 { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                   rc = wait_b_level(); if (rc) return rc;
@@ -1042,25 +959,14 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                 std::swap(psi, t2);
                 hop_ev.emplace_back(e0, e1);
-                h->n_hop_launch += 2;
+                h->n_hop_launch += hoh ? 2 : 1;
                 continue;
-            } else if (MFMA) {
-                // hoh on the matrix cores: t1 = h psi, t2 = (h o) t1, then the per-atom combine/epilogue (VALU) and MFMA orth/update
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, 2 * ll + 1, velems, CV.obase, nb};
-                rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc;
-                SD.level = lv_final;
-                rc = launch_spmm(h, SD, CV, P, 1, hpsi, t2, grid_mf); if (rc) return rc;
+            }
+            // FP64 VALU kernel set: the reference's literal order on the reference's layout
+            if (!hoh) {
+                G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 e1 = next_event(h);
-                G.in = t2; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                k_apply<AM_HOH_LANCZOS, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                k_reduce_a_c2f<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride, afrags);
-                k_mfma_orth<0><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, nullptr, afrags, gpartial);
-                k_reduce_b_eig_mf<<<nb, 1024, 0, h->stream>>>(gpartial, grid_mf.x, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags,
-                                                               h->d_status.as<int>());
-                k_mfma_update<false><<<grid_mf, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, pmn, bfrags);
-                hop_ev.emplace_back(e0, e1);
-                h->n_hop_launch += 2;
-                continue;
             } else {
                 G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
                 k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
@@ -1105,8 +1011,9 @@ extern "C" int rsrec_block_lanczos_seeded(rsrec_t* h, int nchains, int nseed, co
     HIPCK(h, hipSetDevice(h->device));
     reset_timing(h);
     if (nchains == 0) return RSREC_OK;
-    // kernels: 0 = auto (MFMA where implemented), 1 = VALU reference kernels, 2 = MFMA
-    const bool use_mfma = (h->opt_kernels != 1);
+    // kernels: 0 = auto, 1 = FP64 VALU kernel set, 2 = matrix-core set.  The matrix-core SpMM tables exist for lattices with up to
+    // S4_MAXSLOTS - 1 neighbour slots; beyond that the VALU set (any stencil) runs.
+    const bool use_mfma = (h->opt_kernels != 1) && h->s5_built;
     if (use_mfma) return run_block_lanczos<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
     return run_block_lanczos<LayoutCM, false>(h, nchains, nseed, seed_atoms, seed_coef, lld, a_b, b2_b);
 }
@@ -1530,13 +1437,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const int nlev = (hoh ? 2 * napply : napply) + 1;
     const int nmom = 2 * lld + 2;
     const size_t velems = (size_t)(kk + 1) * BLD;
-    // matrix-core epilogue (k_mfma_cheb) and, for large launches, the k-pair SpMM input (k_spmm5): plain Chebyshev only;
-    // hoh keeps the VALU combine kernels
-    const bool s5_ok = h->s5_built && h->opt_spmm4 != 0 && h->opt_spmm5 >= 1;
-    const bool mf_cheb = MFMA && h->opt_post != 1 && (!hoh || s5_ok);
-    // hoh always takes k_spmm5 (its second pass folds the on-site terms in); plain Chebyshev only for large launches
-    const bool use_kp = mf_cheb && s5_ok &&
-                        (hoh || h->opt_spmm5 == 2 || (h->opt_spmm4 < 0 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096));
+    // matrix-core set: k_mfma_cheb epilogue; large launches and hoh use k_spmm5 on CI vectors, small launches of the plain
+    // operator the cooperative k_spmm4<4> on LayoutRM
+    const bool mf_cheb = MFMA;
+    const bool use_kp = MFMA && (hoh || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096) || !spmm4_usable(h));
     const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
     const int ci = use_kp ? 1 : 0;                              // vectors of this call are CI (else LayoutRM / LayoutCM)
     BatchPlan bp;
@@ -1646,22 +1550,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 if (!first) { double* o = p0; p0 = p1; p1 = p2; p2 = o; }
                 continue;
             }
-            if (MFMA) {
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * t - 1 : lv_final, velems, CV.obase, nb};
-                rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc;
-                if (hoh) {
-                    SD.level = lv_final;
-                    rc = launch_spmm(h, SD, CV, P, 1, tmp, tmp2, grid_mf); if (rc) return rc;
-                }
-                G.in = hoh ? tmp2 : tmp; G.v1 = tmp; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
-                if (!hoh) {
-                    if (first) k_apply<AM_CHEB1, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                    else k_apply<AM_CHEBN, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                } else {
-                    if (first) k_apply<AM_HOH_CHEB1, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                    else k_apply<AM_HOH_CHEBN, L, true><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                }
-            } else if (!hoh) {
+            if (!hoh) {
                 G.in = src; G.cur = src; G.v0 = p0; G.out = dst; G.level = lv_final;
                 if (first) k_apply<AM_CHEB1, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
                 else k_apply<AM_CHEBN, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
@@ -1706,7 +1595,7 @@ extern "C" int rsrec_chebyshev_seeded(rsrec_t* h, int nchains, int nseed, const 
     HIPCK(h, hipSetDevice(h->device));
     reset_timing(h);
     if (nchains == 0) return RSREC_OK;
-    if (h->opt_kernels != 1) return run_chebyshev<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n);
+    if (h->opt_kernels != 1 && h->s5_built) return run_chebyshev<LayoutRM, true>(h, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n);
     return run_chebyshev<LayoutCM, false>(h, nchains, nseed, seed_atoms, seed_coef, lld, a, b, mu_n);
 }
 
@@ -1931,6 +1820,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
                 const int ncols = (nl + 1) * NB;
                 const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
                 HIPCK(h, hipGetLastError());
+                HIPCK(h, hipMemsetAsync(Mu.p, 0, (size_t)m_rows * ncols * 16, h->stream));     // (beta = 0 below; the buffer is fresh device memory)
                 // Mu[(m,c), (n,c')] = sum_{k,r} conj(L[(k,r),(m,c)]) R[(k,r),(n,c')]    (zgemm 'C','N'; rocblas_operation codes 113 / 111)
                 if (g_rocblas.zgemm(h->rocblas_handle, 113, 111, m_rows, ncols, (int)ld, one, Lm.p, (int)ld, Rm.p, (int)ld, zero, Mu.p, m_rows) != 0) {
                     cleanup();

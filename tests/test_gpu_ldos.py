@@ -44,6 +44,30 @@ def test_terminator_matches_reference(name):
     rec.close()
 
 
+def test_terminator_many_sites_in_one_call(oracle_lib):
+    """64 sites in one launch (the all-sites call of the drop-in's block_green): every site equals what a one-site call gives, bit
+    for bit, and the CPU oracle's values.  Sites are the bulk bcc Fe coefficients with the levels scaled site by site, so that no
+    two sites run the same bisections."""
+    z = load_green("bccFe_nsp2_block")
+    g = load_golden("bccFe_nsp2_block")
+    ns = 64
+    rec = Recursion(*objects_from(problem_dict(g), np.repeat(g["irec"], ns), g["lld"], nsp=g["nsp"]), device=0)
+    scale = 1.0 + 0.003 * np.arange(ns)
+    rec.a_b[:, :, :, :ns] = z["a_b"][:, :, :, :1] * scale
+    rec.b2_b[:, :, :, :ns] = z["b_sqrt"][:, :, :, :1] * np.sqrt(scale)
+    gr = Green(rec, z["ene"])
+    a_all, b_all, a0, b0 = gr.terminator(nsites=ns)
+    a_o, b_o, _, _ = oracle_lib.terminator(rec.a_b[:, :, :, :ns], rec.b2_b[:, :, :, :ns])
+    assert np.abs(a_all - a_o).max() <= 1e-13 * np.abs(a_o).max() and np.abs(b_all - b_o).max() <= 1e-13 * np.abs(b_o).max()
+    keep_a, keep_b = rec.a_b.copy(), rec.b2_b.copy()
+    for s in (0, 17, 63):
+        rec.a_b[:, :, :, :1] = keep_a[:, :, :, s:s + 1]
+        rec.b2_b[:, :, :, :1] = keep_b[:, :, :, s:s + 1]
+        a1, b1, _, _ = gr.terminator(nsites=1)
+        assert np.array_equal(a1[:, :, 0], a_all[:, :, s]) and np.array_equal(b1[:, :, 0], b_all[:, :, s])
+    rec.close()
+
+
 @pytest.mark.parametrize("name", GREEN_CASES)
 def test_resident_ldos_pipeline(name):
     """recur_b on the GPU, then ONE call for the whole LDOS stage from the coefficients left on the device: terminator and
