@@ -44,9 +44,17 @@ namespace rsrec {
 #endif
 constexpr int S5_FRAG_PER_RB = 320;                         // doubles: pair 0 (128), pair 1 (128), single (64)
 constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 5 * S5_FRAG_PER_RB;   // [sigma_out][sigma_in][rb]
+// "wide" variant (k_spmm5<.., true>): the first 16 real-form rows of a spin go through ONE v_mfma_f64_16x16x4 per tile and k-step
+// instead of four 4x4x4 row blocks -- the same matrix cycles (64 vs 4 x 16), but the operator is delivered in 2 operand registers
+// per k-step instead of 5 (rows 16..19 keep a 4x4x4): 33 instead of 42 operand loads per neighbour slot and 90 instead of 225 MFMA
+// instructions.  Fragments: [sigma_out][sigma_in][2: rows 0..15 | rows 16..19][320].
+constexpr int S5W_FRAG_PER_SLOT = 2 * 2 * 2 * S5_FRAG_PER_RB;
+template <bool WIDE> struct S5Cfg { static constexpr int NA = WIDE ? 2 : 5; static constexpr int FRAG_PER_SLOT = WIDE ? S5W_FRAG_PER_SLOT : S5_FRAG_PER_SLOT; };
 
 struct Spmm5Operator {
     double* d_frag = nullptr;    // [set][tau][slot 0..nslots][sigma_out][sigma_in][rb][320]
+    double* d_fragw = nullptr;   // wide variant: [set][tau][slot 0..nslots][sigma_out][sigma_in][2][320]
+    size_t fragw_bytes = 0;
     int* d_meta = nullptr;       // [set][tau][1 + 2 S4_MAXSLOTS]: count, then entries slot | flip << 8 (flip: input spin = the other spin)
     size_t frag_bytes = 0, meta_bytes = 0;
     int ntau = 0, nslots = 0, have_o = 0;
@@ -54,8 +62,9 @@ struct Spmm5Operator {
 
     void release() {
         if (d_frag) (void)hipFree(d_frag);
+        if (d_fragw) (void)hipFree(d_fragw);
         if (d_meta) (void)hipFree(d_meta);
-        d_frag = nullptr; d_meta = nullptr; frag_bytes = meta_bytes = 0;
+        d_frag = nullptr; d_fragw = nullptr; d_meta = nullptr; frag_bytes = fragw_bytes = meta_bytes = 0;
     }
     // entry (row ko, column ki) of the padded 40x40 real form: index = 20 sigma + rho.  rho = 4 s + l (k-step s, lane row l):
     // s = 2 P + e < 4 -> (part e, m = 4 P + l); s = 4 -> l = 0: (re, m = 8), l = 1: (im, m = 8), l = 2, 3: padding -- the two
@@ -88,6 +97,23 @@ struct Spmm5Operator {
                     }
                 }
     }
+    // wide variant: A operand of the 16x16x4 MFMA for rows 0..15 (lane (l15 = row, l4 = k)), of the 4x4x4 MFMA for rows 16..19
+    static void swizzle_wide(const double* blk, double* out) {
+        for (int so = 0; so < 2; ++so)
+            for (int si = 0; si < 2; ++si) {
+                double* o = out + (so * 2 + si) * 2 * S5_FRAG_PER_RB;
+                for (int l = 0; l < 64; ++l) {
+                    const int k = l >> 4;
+                    for (int part = 0; part < 2; ++part) {
+                        const int ko = 20 * so + (part == 0 ? (l & 15) : 16 + (l & 3));
+                        double* q = o + part * S5_FRAG_PER_RB;
+                        for (int p = 0; p < 2; ++p)
+                            for (int e = 0; e < 2; ++e) q[128 * p + 2 * l + e] = real40(blk, ko, 20 * si + 8 * p + 4 * e + k);
+                        q[256 + l] = real40(blk, ko, 20 * si + 16 + k);
+                    }
+                }
+            }
+    }
     // Set 0: the blocks of h (slot 0 carries + l.s when !hoh).  Set 1 (hoh second pass) is built so that ONE SpMM pass over
     // hpsi = h psi plus one extra on-site slot reading psi gives the whole  H psi = hpsi - (h o) hpsi + (e_nu + l.s) psi
     // (recursion.f90:1543):  slot 0 -> 1 - (h o)_0,  slot s -> -(h o)_s,  slot `nslots` (extra) -> enim + lsham of the atom's type.
@@ -98,8 +124,8 @@ struct Spmm5Operator {
         ntau = nmax + ntype; nslots = nslots_lat; have_o = hoh ? 1 : 0;
         const int nset = have_o ? 2 : 1;
         const int nfs = nslots + 1;
-        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT;
-        std::vector<double> host(per_set * nset, 0.0);
+        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT, per_setw = (size_t)ntau * nfs * S5W_FRAG_PER_SLOT;
+        std::vector<double> host(per_set * nset, 0.0), hostw(per_setw * nset, 0.0);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
         std::vector<double> tmp(2 * BLK);
         for (int set = 0; set < nset; ++set)
@@ -121,12 +147,13 @@ struct Spmm5Operator {
                         }
                     }
                     swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
+                    swizzle_wide(src, hostw.data() + set * per_setw + ((size_t)tau * nfs + s) * S5W_FRAG_PER_SLOT);
                     // schedule: the spin-diagonal part of every block, plus the spin-flip part of blocks that have one
                     M[1 + M[0]] = s; M[0]++;
                     if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
                 }
             }
-        return upload(host, meta);
+        return upload(host, hostw, meta);
     }
     // General table: blk[(set * ntau + tau) * (nslots + 1) + s] = column-major interleaved 18x18 complex block of operator class tau,
     // fragment slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes
@@ -136,8 +163,8 @@ struct Spmm5Operator {
         if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
         ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0;
         const int nfs = nslots + 1;
-        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT;
-        std::vector<double> host(per_set * nset, 0.0);
+        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT, per_setw = (size_t)ntau * nfs * S5W_FRAG_PER_SLOT;
+        std::vector<double> host(per_set * nset, 0.0), hostw(per_setw * nset, 0.0);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
@@ -146,14 +173,22 @@ struct Spmm5Operator {
                     const double* src = blk[((size_t)set * ntau + tau) * nfs + s];
                     if (!src) continue;
                     swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
+                    swizzle_wide(src, hostw.data() + set * per_setw + ((size_t)tau * nfs + s) * S5W_FRAG_PER_SLOT);
                     M[1 + M[0]] = s; M[0]++;
                     if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
                 }
             }
-        return upload(host, meta);
+        return upload(host, hostw, meta);
     }
-    const char* upload(const std::vector<double>& host, const std::vector<int>& meta) {
-        const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
+    const char* upload(const std::vector<double>& host, const std::vector<double>& hostw, const std::vector<int>& meta) {
+        const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int), needw = hostw.size() * sizeof(double);
+        if (needw > fragw_bytes) {
+            if (d_fragw) (void)hipFree(d_fragw);
+            d_fragw = nullptr; fragw_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&d_fragw), needw) != hipSuccess) return "hipMalloc of spmm5 operator fragments failed";
+            fragw_bytes = needw;
+        }
+        if (hipMemcpy(d_fragw, hostw.data(), needw, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 fragments failed";
         if (need > frag_bytes) {
             if (d_frag) (void)hipFree(d_frag);
             d_frag = nullptr; frag_bytes = 0;
@@ -170,13 +205,19 @@ struct Spmm5Operator {
         if (hipMemcpy(d_meta, meta.data(), mneed, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 schedule failed";
         return nullptr;
     }
-    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * (nslots + 1) * S5_FRAG_PER_SLOT; }
+    const double* frag_set(int set, bool wide = false) const {
+        return wide ? d_fragw + (size_t)set * ntau * (nslots + 1) * S5W_FRAG_PER_SLOT : d_frag + (size_t)set * ntau * (nslots + 1) * S5_FRAG_PER_SLOT;
+    }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
 };
 
 typedef double s5_d2 __attribute__((ext_vector_type(2)));
-struct S5Pair { s5_d2 b[9]; s5_d2 a[5]; };      // operands of two k-steps: psi tiles, operator row blocks
-struct S5Single { double b[9]; double a[5]; };  // the spin's fifth k-step (rows 16, 17 + padding)
+template <bool WIDE> struct S5Pair { s5_d2 b[9]; s5_d2 a[S5Cfg<WIDE>::NA]; };      // operands of two k-steps: psi tiles, operator row blocks
+template <bool WIDE> struct S5Single { double b[9]; double a[S5Cfg<WIDE>::NA]; };  // the spin's fifth k-step (row m = 8: re, im + padding)
+// accumulators of a wave: narrow = 5 row blocks x 9 tiles of 4x4x4 results; wide = 9 tiles x (16x16x4 result + 4x4x4 result)
+template <bool WIDE> struct S5Acc;
+template <> struct S5Acc<false> { double v[5][9]; };
+template <> struct S5Acc<true> { double4_t m[9]; double r[9]; };
 
 // wave-uniform addressing state of one neighbour slot
 struct S5Slot {
@@ -185,8 +226,8 @@ struct S5Slot {
     unsigned rem;              // remainder tile: byte offset of this lane's neighbour block (per lane: atom l15 >> 1)
 };
 
-template <int P, bool LOOP = true>
-__device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
+template <int P, bool WIDE, bool LOOP = true>
+__device__ __forceinline__ void s5_load_pair(S5Pair<WIDE>& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
                                              unsigned lane_main, unsigned lane_rem, unsigned lane16) {
     if (!(LOOP && (S5_PROBE & 2))) {
 #pragma unroll
@@ -195,10 +236,11 @@ __device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, unsigne
     }
     if (!(LOOP && (S5_PROBE & 1))) {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
+        for (int rb = 0; rb < S5Cfg<WIDE>::NA; ++rb) o.a[rb] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (rb * S5_FRAG_PER_RB * 8 + 1024 * P));
     }
 }
-__device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
+template <bool WIDE>
+__device__ __forceinline__ void s5_load_single(S5Single<WIDE>& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
                                                unsigned lane_single, unsigned lane_rem_single, unsigned lane8) {
     if (!(S5_PROBE & 2)) {
 #pragma unroll
@@ -210,10 +252,10 @@ __device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, uns
     }
     if (!(S5_PROBE & 1)) {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) o.a[rb] = *reinterpret_cast<const double*>(fb + lane8 + (rb * S5_FRAG_PER_RB * 8 + 2048));
+        for (int rb = 0; rb < S5Cfg<WIDE>::NA; ++rb) o.a[rb] = *reinterpret_cast<const double*>(fb + lane8 + (rb * S5_FRAG_PER_RB * 8 + 2048));
     } else {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb) o.a[rb] = 1e-3 * (rb + 1);
+        for (int rb = 0; rb < S5Cfg<WIDE>::NA; ++rb) o.a[rb] = 1e-3 * (rb + 1);
     }
 }
 
@@ -230,19 +272,35 @@ __device__ __forceinline__ void s5_interleave() {
     __builtin_amdgcn_sched_group_barrier(0x8, NM - PER * NL, 0);
 }
 
-__device__ __forceinline__ void s5_mfma_pair(double (&acc)[5][9], const S5Pair& o) {
+__device__ __forceinline__ void s5_mfma_pair(S5Acc<false>& acc, const S5Pair<false>& o) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int rb = 0; rb < 5; ++rb)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb][e], o.b[t][e], acc[rb][t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) acc.v[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb][e], o.b[t][e], acc.v[rb][t], 0, 0, 0);
 }
-__device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Single& o) {
+__device__ __forceinline__ void s5_mfma_single(S5Acc<false>& acc, const S5Single<false>& o) {
 #pragma unroll
     for (int rb = 0; rb < 5; ++rb)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb], o.b[t], acc[rb][t], 0, 0, 0);
+        for (int t = 0; t < 9; ++t) acc.v[rb][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[rb], o.b[t], acc.v[rb][t], 0, 0, 0);
+}
+__device__ __forceinline__ void s5_mfma_pair(S5Acc<true>& acc, const S5Pair<true>& o) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0][e], o.b[t][e], acc.m[t], 0, 0, 0);
+            acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1][e], o.b[t][e], acc.r[t], 0, 0, 0);
+        }
+}
+__device__ __forceinline__ void s5_mfma_single(S5Acc<true>& acc, const S5Single<true>& o) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0], o.b[t], acc.m[t], 0, 0, 0);
+        acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1], o.b[t], acc.r[t], 0, 0, 0);
+    }
 }
 
 // All schedule entries of a group for one wave (output spin `sig`).  An entry = (neighbour slot, flip): the wave multiplies
@@ -251,8 +309,8 @@ __device__ __forceinline__ void s5_mfma_single(double (&acc)[5][9], const S5Sing
 // single k-step; the operands of the next step are loaded while the MFMAs of the current one run.
 // TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot of the hoh second pass; it reads the second
 // input vector in2b (recursion.f90:1543: H psi = h psi - (h o)(h psi) + (e_nu + l.s) psi, the last term acts on psi itself).
-template <bool TWO>
-__device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ fr_extra, const char* __restrict__ inb,
+template <bool TWO, bool WIDE>
+__device__ __forceinline__ void s5_run_slots(S5Acc<WIDE>& acc, const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ fr_extra, const char* __restrict__ inb,
                                              const char* __restrict__ in2b, const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
                                              int nslots, int sig,
@@ -275,12 +333,13 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
         S.base = base;
         S.rem = (unsigned)nr * (BLD * 8u);
     };
-    const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB);
+    constexpr int NA = S5Cfg<WIDE>::NA, FPS = S5Cfg<WIDE>::FRAG_PER_SLOT;
+    const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * NA * S5_FRAG_PER_RB);
     // fr_extra (TWO only, may be null): fragments of the extra on-site slot taken from a per-chain table instead of the shared one
-    const double* __restrict__ fx_sig = (TWO && fr_extra) ? fr_extra + (size_t)sig * (2 * 5 * S5_FRAG_PER_RB) - (size_t)nslots * S5_FRAG_PER_SLOT : fr_sig;
+    const double* __restrict__ fx_sig = (TWO && fr_extra) ? fr_extra + (size_t)sig * (2 * NA * S5_FRAG_PER_RB) - (size_t)nslots * FPS : fr_sig;
     auto frag_of = [&](int s, int si) {
         const double* __restrict__ base = (TWO && s == nslots) ? fx_sig : fr_sig;
-        return reinterpret_cast<const char*>(base + (size_t)s * S5_FRAG_PER_SLOT + si * (5 * S5_FRAG_PER_RB));
+        return reinterpret_cast<const char*>(base + (size_t)s * FPS + si * (NA * S5_FRAG_PER_RB));
     };
     auto spin_of = [&](int e) { return (e >> 8) ? 1 - sig : sig; };
     S5Slot cur;
@@ -289,10 +348,12 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
     int e_nxt = share[1 + ((1 < nmine) ? 1 % n0 : 0)];
     load_idx(e_cur & 255, nraw, nrem);
     make_slot(nraw, nrem, cur, e_cur & 255);
-    S5Pair X, Y;
-    S5Single Z;
-    s5_load_pair<0, false>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
-    if (S5_PROBE) s5_load_pair<1, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+    S5Pair<WIDE> X, Y;
+    S5Single<WIDE> Z;
+    // operand loads per step / MFMA instructions per step, for the issue interleave
+    constexpr int NL = 9 + NA, NM_PAIR = WIDE ? 36 : 90, NM_SINGLE = WIDE ? 18 : 45;
+    s5_load_pair<0, WIDE, false>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+    if (S5_PROBE) s5_load_pair<1, WIDE, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
     if (S5_VARIANT == 5) { if (sig) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
     for (int j = 0; j < nmine; ++j) {
         const int e_nxt2 = share[1 + ((j + 2 < nmine) ? ((S5_PROBE & 4) ? (j + 2) % n0 : j + 2) : 0)];   // the last entry prefetches the first again (discarded)
@@ -302,18 +363,18 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
         const int si = spin_of(e_cur);
         const unsigned so = 2592u * si;
         const char* __restrict__ fb = frag_of(e_cur & 255, si);
-        s5_load_pair<1>(Y, cur, so, fb, lane_main, lane_rem, lane16);
+        s5_load_pair<1, WIDE>(Y, cur, so, fb, lane_main, lane_rem, lane16);
         s5_mfma_pair(acc, X);
-        s5_interleave<14, 90>();
+        s5_interleave<NL, NM_PAIR>();
         if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
-        s5_load_single(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
+        s5_load_single<WIDE>(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
         s5_mfma_pair(acc, Y);
-        s5_interleave<14, 90>();
+        s5_interleave<NL, NM_PAIR>();
         if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
         make_slot(nraw, nrem, cur, e_nxt & 255);        // the current entry's operands are all in flight or consumed: reuse its state
-        s5_load_pair<0>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
+        s5_load_pair<0, WIDE>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
         s5_mfma_single(acc, Z);
-        s5_interleave<14, 45>();
+        s5_interleave<NL, NM_SINGLE>();
         if (S5_VARIANT != 2) __builtin_amdgcn_sched_barrier(0);
         e_cur = e_nxt;
         e_nxt = e_nxt2;
@@ -323,7 +384,7 @@ __device__ __forceinline__ void s5_run_slots(double (&acc)[5][9], const int* __r
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  Input and output vectors in the CI layout.
 // TWO: second input vector for the extra on-site slot (second pass of hoh; the per-chain on-site term of local-axis runs).
-template <bool TWO>
+template <bool TWO, bool WIDE = false>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
@@ -379,16 +440,21 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
         const unsigned rem_row = (unsigned)(D.nslots + 1) * (unsigned)my_rem_atom;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
-        const double* __restrict__ fr = frag + (size_t)tau * (D.nslots + 1) * S5_FRAG_PER_SLOT;
+        const double* __restrict__ fr = frag + (size_t)tau * (D.nslots + 1) * S5Cfg<WIDE>::FRAG_PER_SLOT;
 
-        double acc[5][9];
+        S5Acc<WIDE> acc;
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int rb = 0; rb < 5; ++rb)
+            for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
+        } else {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[rb][t] = 0.0;
+            for (int rb = 0; rb < 5; ++rb)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc.v[rb][t] = 0.0;
+        }
 
-        const double* __restrict__ fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * S5_FRAG_PER_SLOT : nullptr;
-        s5_run_slots<TWO>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        const double* __restrict__ fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * S5Cfg<WIDE>::FRAG_PER_SLOT : nullptr;
+        s5_run_slots<TWO, WIDE>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
         // D layout: real-form row rho = 4 rb + l4 of spin sig, column l15.  rb = 2 P + e is (part e, m = 4 P + l4): the accumulators
         // (2P, 2P+1) are the real and imaginary part of element (m, c) -> one 16-byte store in the CI layout; rb = 4: m = 8
@@ -397,12 +463,15 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             const int a = (t < 8) ? atom[t] : my_rem_atom;
             if (a == zero_block) continue;
             double* ob = out + (size_t)BLD * a + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1));
+            // (wide: the 16x16x4 result register j holds row l4 + 4 j of the spin = (part j & 1, m = l4 + 4 (j >> 1)): the same pairing)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                s5_d2 v; v[0] = acc[2 * p][t]; v[1] = acc[2 * p + 1][t];
+                s5_d2 v;
+                if constexpr (WIDE) { v[0] = acc.m[t][2 * p]; v[1] = acc.m[t][2 * p + 1]; }
+                else { v[0] = acc.v[2 * p][t]; v[1] = acc.v[2 * p + 1][t]; }
                 *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
             }
-            if (l4 < 2) ob[288 + l4] = acc[4][t];
+            if (l4 < 2) { if constexpr (WIDE) ob[288 + l4] = acc.r[t]; else ob[288 + l4] = acc.v[4][t]; }
         }
     }
     }   // chains of this workgroup

@@ -94,7 +94,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_wide = 0;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -350,6 +350,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
+    else if (!strcmp(key, "spmm5_wide")) h->opt_wide = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -764,6 +765,16 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
     return out;
 }
 
+// k_spmm5 launch: narrow (4x4x4 everywhere) or wide (16x16x4 for the first 16 rows) variant, option "spmm5_wide"
+template <bool TWO>
+void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
+               const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
+    if (h->opt_wide)
+        k_spmm5<TWO, true><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
+    else
+        k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, false), op.meta_set(set), in, out, in2, extra, ntau);
+}
+
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
 bool spmm4_usable(const rsrec_t* h) { return h->s4_built_split && (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32); }
 
@@ -797,7 +808,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     if (rot && !MFMA) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set (option kernels = 0 or 2)");
     const int ntau = h->nmax + h->ntype;
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
-    if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * S5_FRAG_PER_SLOT * sizeof(double)));
+    const int la_fps = h->opt_wide ? S5W_FRAG_PER_SLOT : S5_FRAG_PER_SLOT;
+    if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * la_fps * sizeof(double)));
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -858,7 +870,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         const double* la_extra = nullptr;
         if (rot) {
             // per-chain on-site term of the local-axis operator in the GLOBAL frame: (e_nu +) R l.s R^H  (see rsrec_block_lanczos_local_axis)
-            std::vector<double> fr((size_t)nb * ntau * S5_FRAG_PER_SLOT), E(2 * BLK), T(2 * BLK);
+            std::vector<double> fr((size_t)nb * ntau * la_fps), E(2 * BLK), T(2 * BLK);
             for (int c = 0; c < nb; ++c) {
                 const double* R = rot + 2 * (size_t)BLK * (c0 + c);
                 for (int tau = 0; tau < ntau; ++tau) {
@@ -883,7 +895,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             E[2 * (i + NB * j)] = sr; E[2 * (i + NB * j) + 1] = si;
                         }
                     if (hoh) for (int e = 0; e < 2 * BLK; ++e) E[e] += h->host_enim[2 * (size_t)BLK * ty + e];
-                    Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * S5_FRAG_PER_SLOT);
+                    if (h->opt_wide) Spmm5Operator::swizzle_wide(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
+                    else Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
                 }
             }
             XFER(xfer_h2d(h, h->d_la_extra.p, fr.data(), fr.size() * sizeof(double)));
@@ -939,15 +952,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                 // matrix-core kernel set, un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * ll + 1 : lv_final, velems, CV.obase, nb};
                 if (!hoh) {
-                    if (ci && rot) k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi, psi, la_extra, ntau);
-                    else if (ci) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hpsi);
+                    if (ci && rot) launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi, psi, la_extra, ntau);
+                    else if (ci) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi);
                     else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
                 } else {
                     // H = h - (h o) h + e_nu + l.s in two passes of k_spmm5: h psi, then the rest with psi as second input (extra on-site slot)
                     double* hps = pmn;                   // (the pmn buffer is free in the u-scheme)
-                    k_spmm5<false><<<s5_grid(h, grid_mf, 2 * ll + 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(0), OP.meta_set(0), psi, hps);
+                    launch_s5<false>(h, s5_grid(h, grid_mf, 2 * ll + 1), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hps);
                     SD.level = lv_final;
-                    k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, OP.frag_set(1), OP.meta_set(1), hps, hpsi, psi, la_extra, ntau);
+                    launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 1, hps, hpsi, psi, la_extra, ntau);
                 }
                 e1 = next_event(h);
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
@@ -1526,10 +1539,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
                 if (hoh) {
                     SD.level = 2 * t - 1;
-                    k_spmm5<false><<<s5_grid(h, grid_mf, 2 * t - 1), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), src, hps);
+                    launch_s5<false>(h, s5_grid(h, grid_mf, 2 * t - 1), SD, CV.order, CV.cum, P.iz, h->s5_op, 0, src, hps);
                     SD.level = lv_final;
-                    k_spmm5<true><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(1), h->s5_op.meta_set(1), hps, tmp, src);
-                } else if (use_kp) k_spmm5<false><<<s5_grid(h, grid_mf, lv_final), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, CV.order, CV.cum, h->d_nbr5.as<int>(), P.iz, h->s5_op.frag_set(0), h->s5_op.meta_set(0), src, tmp);
+                    launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 1, hps, tmp, src);
+                } else if (use_kp) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 0, src, tmp);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
@@ -1689,8 +1702,8 @@ struct KuboCtx {
 
 void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double* in, double* out, const double* in2) {
     rsrec_t* h = K.h;
-    if (in2) k_spmm5<true><<<K.grid, S5_WG_GROUPS * 128, 0, h->stream>>>(K.SD, K.CV.order, K.CV.cum, h->d_nbr5.as<int>(), K.iz, op.frag_set(set), op.meta_set(set), in, out, in2);
-    else k_spmm5<false><<<K.grid, S5_WG_GROUPS * 128, 0, h->stream>>>(K.SD, K.CV.order, K.CV.cum, h->d_nbr5.as<int>(), K.iz, op.frag_set(set), op.meta_set(set), in, out);
+    if (in2) launch_s5<true>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, in2);
+    else launch_s5<false>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out);
 }
 // out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift)
 void kubo_apply_h(const KuboCtx& K, const double* in, double* out) {

@@ -179,7 +179,8 @@ def test_config2_size_1e5_atoms():
     rec.close()
 
 
-@pytest.mark.parametrize("opts", [{"spmm5": 0}, {"spmm5": 2}, {"spmm5": 2, "side_stream": 0}, {"spmm5": 0, "side_stream": 0}, {"batch": 1}])
+@pytest.mark.parametrize("opts", [{"spmm5": 0}, {"spmm5": 2}, {"spmm5": 2, "side_stream": 0}, {"spmm5": 0, "side_stream": 0}, {"batch": 1},
+                                  {"spmm5": 2, "spmm5_wide": 0}, {"spmm5": 2, "spmm5_wide": 1}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """Both SpMM kernels of the matrix-core set (small-launch k_spmm4<4> on LayoutRM vectors, k_spmm5 on CI vectors), with and without
@@ -261,8 +262,30 @@ def test_errors_are_loud():
     rec.close()
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("name", BLOCK_CASES + CHEB_CASES)
+def test_both_spmm5_variants_on_every_fixture(name, wide):
+    """k_spmm5 narrow (4x4x4 row blocks) and wide (16x16x4 for the first 16 rows of a spin) on every block / Chebyshev fixture
+    (bulk, hoh, impurity, surface, non-collinear)."""
+    g = load_golden(name)
+    cheb = name in CHEB_CASES
+    rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], **({"emin": g["emin"], "emax": g["emax"]} if cheb else {}))
+    rec.set_option("kernels", 2)
+    rec.set_option("spmm5", 2)
+    rec.set_option("spmm5_wide", wide)
+    n = g["nrec"]
+    if cheb:
+        rec.chebyshev_recur()
+        assert rel_err(rec.mu_n[:, :, :, :n], g["mu_n"]) < RTOL
+    else:
+        rec.recur_b()
+        assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL and rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("name", ["Pt2MnGa_nsp4_local_axis", "Pt2MnGa_nsp4_local_axis_hoh"])
-def test_local_axis_batched_block_lanczos(name):
+def test_local_axis_batched_block_lanczos(name, wide):
     """hamiltonian%local_axis = T (recursion.f90:1830-1832): four sites (Mn, Ga, Pt1, Pt2) with four different moment directions,
     every chain in ITS spin frame.  The reference rotates all blocks per site and runs the sites one by one; here all four chains
     go in one call on the global-frame blocks (per-chain on-site l.s term + conjugation of the outputs).  Fixture: the compiled
@@ -272,6 +295,7 @@ def test_local_axis_batched_block_lanczos(name):
     moms = g["mom"].T
     assert len({tuple(np.round(m, 6)) for m in moms}) == 4                 # four inequivalent directions
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
+    rec.set_option("spmm5_wide", wide)
     rec.recur_b_local_axis(g["rot"])
     n = g["nrec"]
     assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL
