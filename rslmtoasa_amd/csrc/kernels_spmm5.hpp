@@ -309,7 +309,7 @@ __device__ __forceinline__ void s5_mfma_single(S5Acc<true>& acc, const S5Single<
 // single k-step; the operands of the next step are loaded while the MFMAs of the current one run.
 // TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot of the hoh second pass; it reads the second
 // input vector in2b (recursion.f90:1543: H psi = h psi - (h o)(h psi) + (e_nu + l.s) psi, the last term acts on psi itself).
-template <bool TWO, bool WIDE>
+template <bool TWO, bool WIDE, int PF = 1>
 __device__ __forceinline__ void s5_run_slots(S5Acc<WIDE>& acc, const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ fr_extra, const char* __restrict__ inb,
                                              const char* __restrict__ in2b, const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
@@ -353,8 +353,36 @@ __device__ __forceinline__ void s5_run_slots(S5Acc<WIDE>& acc, const int* __rest
     // operand loads per step / MFMA instructions per step, for the issue interleave
     constexpr int NL = 9 + NA, NM_PAIR = WIDE ? 36 : 90, NM_SINGLE = WIDE ? 18 : 45;
     s5_load_pair<0, WIDE, false>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
-    if (S5_PROBE) s5_load_pair<1, WIDE, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+    if (S5_PROBE || PF == 2) s5_load_pair<1, WIDE, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
     if (S5_VARIANT == 5) { if (sig) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+    if (PF == 2) {
+        // Prefetch distance TWO steps with the same three register sets: while step X runs, Y (issued one step ago) and Z (issued
+        // now) are in flight; a set is reloaded right after the step that consumed it.  (Distance one left every load a single
+        // step -- 1440 matrix cycles -- to arrive; gathers that miss L2 take longer.)
+        for (int j = 0; j < nmine; ++j) {
+            const int e_nxt2 = share[1 + ((j + 2 < nmine) ? ((S5_PROBE & 4) ? (j + 2) % n0 : j + 2) : 0)];
+            load_idx(e_nxt & 255, nraw, nrem);
+            const int si = spin_of(e_cur);
+            const unsigned so = 2592u * si;
+            const char* __restrict__ fb = frag_of(e_cur & 255, si);
+            s5_load_single<WIDE>(Z, cur, so, fb, lane_single, lane_rem_single, lane8);     // Z(e): the last load of this entry
+            s5_mfma_pair(acc, X);
+            s5_interleave<NL, NM_PAIR>();
+            __builtin_amdgcn_sched_barrier(0);
+            make_slot(nraw, nrem, cur, e_nxt & 255);
+            s5_load_pair<0, WIDE>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
+            s5_mfma_pair(acc, Y);
+            s5_interleave<NL, NM_PAIR>();
+            __builtin_amdgcn_sched_barrier(0);
+            s5_load_pair<1, WIDE>(Y, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
+            s5_mfma_single(acc, Z);
+            s5_interleave<NL, NM_SINGLE>();
+            __builtin_amdgcn_sched_barrier(0);
+            e_cur = e_nxt;
+            e_nxt = e_nxt2;
+        }
+        return;
+    }
     for (int j = 0; j < nmine; ++j) {
         const int e_nxt2 = share[1 + ((j + 2 < nmine) ? ((S5_PROBE & 4) ? (j + 2) % n0 : j + 2) : 0)];   // the last entry prefetches the first again (discarded)
         load_idx(e_nxt & 255, nraw, nrem);
@@ -384,7 +412,7 @@ __device__ __forceinline__ void s5_run_slots(S5Acc<WIDE>& acc, const int* __rest
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  Input and output vectors in the CI layout.
 // TWO: second input vector for the extra on-site slot (second pass of hoh; the per-chain on-site term of local-axis runs).
-template <bool TWO, bool WIDE = false>
+template <bool TWO, bool WIDE = false, int PF = 1>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         }
 
         const double* __restrict__ fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * S5Cfg<WIDE>::FRAG_PER_SLOT : nullptr;
-        s5_run_slots<TWO, WIDE>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_slots<TWO, WIDE, PF>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
 
         // D layout: real-form row rho = 4 rb + l4 of spin sig, column l15.  rb = 2 P + e is (part e, m = 4 P + l4): the accumulators
         // (2P, 2P+1) are the real and imaginary part of element (m, c) -> one 16-byte store in the CI layout; rb = 4: m = 8
