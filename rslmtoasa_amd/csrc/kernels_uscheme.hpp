@@ -143,32 +143,48 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     // set is never copied while its loads are in flight (a register copy of a load target waits for the load -- the rotating
     // copies of round 1 cut the effective prefetch distance to one tile: 38 % of the wave cycles sat in s_waitcnt,
     // profiles/r02b_c2_sq_pmc.txt).  Loads of tile it + 2 are issued before the MFMAs of tile it.
-    auto compute_tile = [&](int it, const U3Operands& ot, const U3Operands& oc, const U3Operands& op) {
-        const TileAtoms ta = tile_atoms(it);
-        const int mt = it % 9;
-        double4_t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
-        double cr = 0.0;
-        u3_mac(ca, cb, cr, ot, T1, l4 & 1);
-        u3_mac(ca, cb, cr, op, T2, l4 & 1);
-        u3_mac(ca, cb, cr, oc, T3, l4 & 1);
+    // Software pipeline across row tiles: the stores and the Gram update of tile it - 1 are issued in the middle of tile it's
+    // multiplications.  With one wave per SIMD nothing else covers the tail of a tile (the stores and the Gram MFMAs need the last
+    // MFMA results, the Gram's third operand a cross-lane shuffle of them): run back to back that tail idled the matrix pipe for
+    // about a third of each tile (profiles/r02i_c2_sq_pmc.txt: pipe 56 % busy, 68 % of the wave cycles in issue stalls).
+    struct Pending { double4_t ca, cb; double cr; TileAtoms ta; int mt; };
+    Pending P;
+    bool pending = false;
+    auto retire = [&](const double (&fr)[4]) {                 // stores + Gram update of the pending tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const RowRef rs = tile_row(ta, 16 * mt + l4 + 4 * j);
-            if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
+            const RowRef rs = tile_row(P.ta, 16 * P.mt + l4 + 4 * j);
+            if (rs.valid) { up[rs.off + l15] = P.ca[j]; up[rs.off + 16 + l15] = P.cb[j]; }
         }
-        const RowRef rr = tile_row(ta, 16 * mt + 4 * lg + l4);
-        if (rr.valid) up[rr.off + 32 + l3] = cr;
+        const RowRef rr = tile_row(P.ta, 16 * P.mt + 4 * lg + l4);
+        if (rr.valid) up[rr.off + 32 + l3] = P.cr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double f0 = ca[j], f1 = cb[j];
-            const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);
+            const double f0 = P.ca[j], f1 = P.cb[j];
             Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
             Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
             Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
-            Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
-            Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
-            Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
+            Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[j], f0, Gm.tr0, 0, 0, 0);
+            Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[j], f1, Gm.tr1, 0, 0, 0);
+            Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr[j], fr[j], Gm.trr, 0, 0, 0);
         }
+    };
+    auto compute_tile = [&](int it, const U3Operands& ot, const U3Operands& oc, const U3Operands& op) {
+        double fr[4] = {0.0, 0.0, 0.0, 0.0};
+        if (pending) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fr[j] = __shfl(P.cr, l3 + 4 * j + 16 * l4, 64);     // Y[row 4j + l4][32 + l3] of the pending tile
+        }
+        Pending N;
+        N.ta = tile_atoms(it);
+        N.mt = it % 9;
+        N.ca = (double4_t){0, 0, 0, 0}; N.cb = (double4_t){0, 0, 0, 0}; N.cr = 0.0;
+        u3_mac(N.ca, N.cb, N.cr, ot, T1, l4 & 1);
+        if (pending) retire(fr);
+        u3_mac(N.ca, N.cb, N.cr, op, T2, l4 & 1);
+        u3_mac(N.ca, N.cb, N.cr, oc, T3, l4 & 1);
+        P = N;
+        pending = true;
     };
     U3Operands at, ac, ap, bt, bc, bp, ct, cc, cp;
     if (ntile > 0) { load_tile(0, at, ac, ap); load_tile(1, bt, bc, bp); }
@@ -192,6 +208,12 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
             compute_tile(it + 2, ct, cc, cp);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (pending) {                                             // drain the pipeline: the last tile of this wave
+        double fr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fr[j] = __shfl(P.cr, l3 + 4 * j + 16 * l4, 64);
+        retire(fr);
     }
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }
