@@ -505,4 +505,155 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     }   // chains of this workgroup
 }
 
+// "Streamed" variant of the wide kernel: a wave walks SEVERAL groups and treats their schedule entries as one stream -- the first
+// operands of the next group are requested during the last entry of the current one (prefetch distance two steps, as inside a
+// group), so the group prologue (order list -> atoms -> operator class -> schedule -> neighbour table -> first operand loads, a
+// chain of dependent loads of 3-5 us against 25 us of work) and the result stores of the finished group overlap with matrix work
+// instead of idling the CU: with one 8-wave workgroup per CU nothing else covers them (matrix pipe 70 % busy,
+// profiles/r02l_c2_sq_pmc.txt).  Launched with fewer, longer-lived workgroups (option "s5_items" groups per wave).
+struct S5Group {
+    int atom[GROUP];           // wave-uniform: the eight atoms (padding -> zero block)
+    int rem_atom;              // per lane: atom of the lane's remainder-tile column
+    unsigned rem_row;          // per lane: (nslots + 1) * rem_atom
+    const int* M;              // schedule of the group's operator class: count, entries
+    const double* fr;          // fragments of the class, this wave's output spin
+    const double* fx;          // per-chain extra-slot fragments (same offset convention as fr) or fr
+};
+
+template <bool TWO>
+__global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5s(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
+                                               const int* __restrict__ nbr, const int* __restrict__ izp, const double* __restrict__ frag,
+                                               const int* __restrict__ meta, const double* __restrict__ in_all, double* __restrict__ out_all,
+                                               const double* __restrict__ in2_all = nullptr, const double* __restrict__ frag_extra = nullptr, int ntau = 0) {
+    constexpr bool WIDE = true;
+    constexpr int NA = S5Cfg<WIDE>::NA, FPS = S5Cfg<WIDE>::FRAG_PER_SLOT, NL = 9 + NA, NM_PAIR = 36, NM_SINGLE = 18;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const unsigned lane_main = 8u * (36 * l4 + 2 * l15), lane_single = 8u * (288 + 2 * l15 + (l4 & 1));
+    const unsigned lane_rem = 8u * (36 * l4 + 32 + 2 * (l15 & 1)), lane_rem_single = 8u * (288 + 32 + 2 * (l15 & 1) + (l4 & 1));
+    const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
+    const int nslots = D.nslots, nstride = D.nslots + 1;
+#pragma unroll 1
+    for (int chain = blockIdx.y; chain < D.nchains; chain += gridDim.y) {
+        const int count = cum[(chain / D.cpo) * D.nlev + D.level];
+        const int ngroups = count / GROUP;
+        const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
+        const size_t vo = (size_t)chain * D.vstride;
+        const char* __restrict__ inb = reinterpret_cast<const char*>(in_all + vo);
+        const char* __restrict__ in2b = TWO ? reinterpret_cast<const char*>(in2_all + vo) : nullptr;
+        double* __restrict__ out = out_all + vo;
+        const int zero_block = D.kk;
+        int g, gend, gstep;
+        {
+            const int nbx = max(1, min((int)gridDim.x, (ngroups + S5_WG_GROUPS - 1) / S5_WG_GROUPS)), bx = blockIdx.x;
+            if (bx >= nbx) continue;
+            if (nbx < 8) { g = bx * S5_WG_GROUPS + gslot; gend = ngroups; gstep = nbx * S5_WG_GROUPS; }
+            else {
+                const int xcd = bx & 7, j = bx >> 3;
+                const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
+                const int chunk = (ngroups + 7) >> 3;
+                const int lo = xcd * chunk;
+                gend = min(ngroups, lo + chunk);
+                g = lo + j * S5_WG_GROUPS + gslot;
+                gstep = per_xcd * S5_WG_GROUPS;
+            }
+        }
+        if (g >= gend) continue;
+        auto load_group = [&](int gg, S5Group& G) {
+            const int* __restrict__ grp = order + (size_t)gg * GROUP;
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; G.atom[t] = a >= 0 ? a : zero_block; }
+            const int first = G.atom[0];
+            const int tau = first < D.nmax ? first : D.nmax + izp[first];
+            int ra = grp[l15 >> 1];
+            G.rem_atom = ra >= 0 ? ra : zero_block;
+            G.rem_row = (unsigned)nstride * (unsigned)G.rem_atom;
+            G.M = meta + (size_t)tau * Spmm5Operator::META;
+            G.fr = frag + (size_t)tau * nstride * FPS + (size_t)sig * (2 * NA * S5_FRAG_PER_RB);
+            G.fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * FPS + (size_t)sig * (2 * NA * S5_FRAG_PER_RB) - (size_t)nslots * FPS : G.fr;
+        };
+        auto load_idx = [&](const S5Group& G, int s, int (&n)[GROUP], int& nr) {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) n[t] = nbr[(size_t)nstride * G.atom[t] + s];
+            nr = nbr[G.rem_row + (unsigned)s];
+        };
+        auto make_slot = [&](const int (&n)[GROUP], int nr, S5Slot& S, int s) {
+            const char* base = (TWO && s == nslots) ? in2b : inb;
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) S.tile[t] = base + (size_t)n[t] * (BLD * 8);
+            S.base = base;
+            S.rem = (unsigned)nr * (BLD * 8u);
+        };
+        auto frag_of = [&](const S5Group& G, int s, int si) {
+            const double* __restrict__ base = (TWO && s == nslots) ? G.fx : G.fr;
+            return reinterpret_cast<const char*>(base + (size_t)s * FPS + si * (NA * S5_FRAG_PER_RB));
+        };
+        auto spin_of = [&](int e) { return (e >> 8) ? 1 - sig : sig; };
+
+        S5Group G, Gn;
+        load_group(g, G);
+        S5Slot cur;
+        int nraw[GROUP], nrem;
+        int e_cur = G.M[1];
+        load_idx(G, e_cur & 255, nraw, nrem);
+        make_slot(nraw, nrem, cur, e_cur & 255);
+        S5Pair<WIDE> X, Y;
+        S5Single<WIDE> Z;
+        s5_load_pair<0, WIDE, false>(X, cur, 2592u * spin_of(e_cur), frag_of(G, e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+        s5_load_pair<1, WIDE, false>(Y, cur, 2592u * spin_of(e_cur), frag_of(G, e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
+#pragma unroll 1
+        for (;;) {
+            const int gn = g + gstep;
+            const bool has_next = gn < gend;
+            if (has_next) load_group(gn, Gn); else Gn = G;         // (no next group: the final prefetch re-reads this group's first entry, discarded)
+            S5Acc<WIDE> acc;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
+            const int n = G.M[0];
+#pragma unroll 1
+            for (int j = 0; j < n; ++j) {
+                const bool last = (j + 1 == n);
+                const int e_nxt = last ? Gn.M[1] : G.M[2 + j];
+                if (last) load_idx(Gn, e_nxt & 255, nraw, nrem); else load_idx(G, e_nxt & 255, nraw, nrem);
+                const int si = spin_of(e_cur);
+                const unsigned so = 2592u * si;
+                const char* __restrict__ fb = frag_of(G, e_cur & 255, si);
+                s5_load_single<WIDE>(Z, cur, so, fb, lane_single, lane_rem_single, lane8);
+                s5_mfma_pair(acc, X);
+                s5_interleave<NL, NM_PAIR>();
+                __builtin_amdgcn_sched_barrier(0);
+                make_slot(nraw, nrem, cur, e_nxt & 255);
+                const char* __restrict__ fbn = last ? frag_of(Gn, e_nxt & 255, spin_of(e_nxt)) : frag_of(G, e_nxt & 255, spin_of(e_nxt));
+                s5_load_pair<0, WIDE>(X, cur, 2592u * spin_of(e_nxt), fbn, lane_main, lane_rem, lane16);
+                s5_mfma_pair(acc, Y);
+                s5_interleave<NL, NM_PAIR>();
+                __builtin_amdgcn_sched_barrier(0);
+                s5_load_pair<1, WIDE>(Y, cur, 2592u * spin_of(e_nxt), fbn, lane_main, lane_rem, lane16);
+                s5_mfma_single(acc, Z);
+                s5_interleave<NL, NM_SINGLE>();
+                __builtin_amdgcn_sched_barrier(0);
+                e_cur = e_nxt;
+            }
+            // results of group G (the next group's first operands are in flight meanwhile)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int a = (t < 8) ? G.atom[t] : G.rem_atom;
+                if (a == zero_block) continue;
+                double* ob = out + (size_t)BLD * a + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1));
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    s5_d2 v; v[0] = acc.m[t][2 * p]; v[1] = acc.m[t][2 * p + 1];
+                    *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
+                }
+                if (l4 < 2) ob[288 + l4] = acc.r[t];
+            }
+            if (!has_next) break;
+            G = Gn;
+            g = gn;
+        }
+    }
+}
+
 }  // namespace rsrec

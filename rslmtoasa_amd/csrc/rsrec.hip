@@ -94,7 +94,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_wide = 1, opt_pf = 2;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_wide = 1, opt_pf = 2, opt_items = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -352,6 +352,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else if (!strcmp(key, "spmm5_wide")) h->opt_wide = value;
     else if (!strcmp(key, "s5_pf")) h->opt_pf = value;
+    else if (!strcmp(key, "s5_items")) h->opt_items = std::max<long>(1, value);
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -770,7 +771,9 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
-    if (h->opt_wide && h->opt_pf == 2)
+    if (h->opt_wide && h->opt_pf == 2 && h->opt_items > 1)
+        k_spmm5s<TWO><<<dim3((grid.x + (unsigned)h->opt_items - 1) / (unsigned)h->opt_items, grid.y), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
+    else if (h->opt_wide && h->opt_pf == 2)
         k_spmm5<TWO, true, 2><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
     else if (h->opt_wide)
         k_spmm5<TWO, true><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);

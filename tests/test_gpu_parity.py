@@ -180,7 +180,8 @@ def test_config2_size_1e5_atoms():
 
 
 @pytest.mark.parametrize("opts", [{"spmm5": 0}, {"spmm5": 2}, {"spmm5": 2, "side_stream": 0}, {"spmm5": 0, "side_stream": 0}, {"batch": 1},
-                                  {"spmm5": 2, "spmm5_wide": 0}, {"spmm5": 2, "spmm5_wide": 1}, {"spmm5": 2, "spmm5_wide": 1, "s5_pf": 2}])
+                                  {"spmm5": 2, "spmm5_wide": 0}, {"spmm5": 2, "spmm5_wide": 1}, {"spmm5": 2, "spmm5_wide": 1, "s5_pf": 2},
+                                  {"spmm5": 2, "s5_items": 2}, {"spmm5": 2, "s5_items": 5}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """Both SpMM kernels of the matrix-core set (small-launch k_spmm4<4> on LayoutRM vectors, k_spmm5 on CI vectors), with and without
@@ -262,7 +263,7 @@ def test_errors_are_loud():
     rec.close()
 
 
-@pytest.mark.parametrize("wide", [0, 1, 2])
+@pytest.mark.parametrize("wide", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", BLOCK_CASES + CHEB_CASES)
 def test_both_spmm5_variants_on_every_fixture(name, wide):
     """k_spmm5 narrow (4x4x4 row blocks) and wide (16x16x4 for the first 16 rows of a spin) on every block / Chebyshev fixture
@@ -273,7 +274,8 @@ def test_both_spmm5_variants_on_every_fixture(name, wide):
     rec.set_option("kernels", 2)
     rec.set_option("spmm5", 2)
     rec.set_option("spmm5_wide", min(wide, 1))
-    rec.set_option("s5_pf", 2 if wide == 2 else 1)                       # wide = 2: the wide variant with operand prefetch two steps ahead
+    rec.set_option("s5_pf", 2 if wide >= 2 else 1)                       # wide = 2: the wide variant with operand prefetch two steps ahead
+    rec.set_option("s5_items", 3 if wide == 3 else 1)                    # wide = 3: streamed over three groups per wave (k_spmm5s)
     n = g["nrec"]
     if cheb:
         rec.chebyshev_recur()
