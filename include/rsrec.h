@@ -206,7 +206,6 @@ int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
  *   "kernels"    0 = auto, 1 = FP64 VALU kernel set (the reference's layout and operation order; any stencil), 2 = matrix-core set [0]
  *   "spmm5"      SpMM of the matrix-core set: 0 = small-launch kernel k_spmm4<4> (LayoutRM vectors), 1 = by launch size (k_spmm5 on CI
  *                vectors from 4096 groups per launch; always for hoh and local-axis runs), 2 = always k_spmm5 [1]
- *   "spmm5_wide" k_spmm5 variant: 0 = 4x4x4 MFMA row blocks, 1 = one 16x16x4 MFMA for the first 16 rows of a spin [see DESIGN.md]
  *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u> [1]
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
  *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none] */

@@ -94,7 +94,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_wide = 1, opt_pf = 2, opt_items = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
@@ -350,9 +350,6 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
-    else if (!strcmp(key, "spmm5_wide")) h->opt_wide = value;
-    else if (!strcmp(key, "s5_pf")) h->opt_pf = value;
-    else if (!strcmp(key, "s5_items")) h->opt_items = std::max<long>(1, value);
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -767,18 +764,11 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
     return out;
 }
 
-// k_spmm5 launch: narrow (4x4x4 everywhere) or wide (16x16x4 for the first 16 rows) variant, option "spmm5_wide"
+// k_spmm5 launch (large launches; CI vectors)
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
-    if (h->opt_wide && h->opt_pf == 2 && h->opt_items > 1)
-        k_spmm5s<TWO><<<dim3((grid.x + (unsigned)h->opt_items - 1) / (unsigned)h->opt_items, grid.y), S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
-    else if (h->opt_wide && h->opt_pf == 2)
-        k_spmm5<TWO, true, 2><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
-    else if (h->opt_wide)
-        k_spmm5<TWO, true><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, true), op.meta_set(set), in, out, in2, extra, ntau);
-    else
-        k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set, false), op.meta_set(set), in, out, in2, extra, ntau);
+    k_spmm5<TWO><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), in, out, in2, extra, ntau);
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
@@ -814,7 +804,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     if (rot && !MFMA) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set (option kernels = 0 or 2)");
     const int ntau = h->nmax + h->ntype;
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
-    const int la_fps = h->opt_wide ? S5W_FRAG_PER_SLOT : S5_FRAG_PER_SLOT;
+    const int la_fps = S5_FRAG_PER_SLOT;
     if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * la_fps * sizeof(double)));
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
@@ -901,8 +891,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             E[2 * (i + NB * j)] = sr; E[2 * (i + NB * j) + 1] = si;
                         }
                     if (hoh) for (int e = 0; e < 2 * BLK; ++e) E[e] += h->host_enim[2 * (size_t)BLK * ty + e];
-                    if (h->opt_wide) Spmm5Operator::swizzle_wide(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
-                    else Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
+                    Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
                 }
             }
             XFER(xfer_h2d(h, h->d_la_extra.p, fr.data(), fr.size() * sizeof(double)));

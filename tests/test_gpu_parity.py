@@ -16,12 +16,12 @@ from rslmtoasa_amd.recursion import Recursion
 pytestmark = pytest.mark.gpu
 
 KERNELS = [1, 2]   # 1 = VALU reference kernels, 2 = MFMA kernels (both are HIP; both must meet the bar)
-# "kp": MFMA kernels with the large-launch SpMM (k_spmm5, k-pair vector layout) forced on the small fixtures too
-BLOCK_VARIANTS = [1, 2, "kp"]
+# "ci": matrix-core kernels with the large-launch SpMM (k_spmm5, CI vector layout) forced on the small fixtures too
+BLOCK_VARIANTS = [1, 2, "ci"]
 
 
 def select_kernels(rec, variant):
-    if variant == "kp":
+    if variant == "ci":
         rec.set_option("kernels", 2)
         rec.set_option("spmm5", 2)
     else:
@@ -180,8 +180,7 @@ def test_config2_size_1e5_atoms():
 
 
 @pytest.mark.parametrize("opts", [{"spmm5": 0}, {"spmm5": 2}, {"spmm5": 2, "side_stream": 0}, {"spmm5": 0, "side_stream": 0}, {"batch": 1},
-                                  {"spmm5": 2, "spmm5_wide": 0}, {"spmm5": 2, "spmm5_wide": 1}, {"spmm5": 2, "spmm5_wide": 1, "s5_pf": 2},
-                                  {"spmm5": 2, "s5_items": 2}, {"spmm5": 2, "s5_items": 5}])
+                                  {"spmm5": 2, "chain_fold": 2}, {"spmm5": 2, "s5_cap": 8}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """Both SpMM kernels of the matrix-core set (small-launch k_spmm4<4> on LayoutRM vectors, k_spmm5 on CI vectors), with and without
@@ -263,32 +262,8 @@ def test_errors_are_loud():
     rec.close()
 
 
-@pytest.mark.parametrize("wide", [0, 1, 2, 3])
-@pytest.mark.parametrize("name", BLOCK_CASES + CHEB_CASES)
-def test_both_spmm5_variants_on_every_fixture(name, wide):
-    """k_spmm5 narrow (4x4x4 row blocks) and wide (16x16x4 for the first 16 rows of a spin) on every block / Chebyshev fixture
-    (bulk, hoh, impurity, surface, non-collinear)."""
-    g = load_golden(name)
-    cheb = name in CHEB_CASES
-    rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"], **({"emin": g["emin"], "emax": g["emax"]} if cheb else {}))
-    rec.set_option("kernels", 2)
-    rec.set_option("spmm5", 2)
-    rec.set_option("spmm5_wide", min(wide, 1))
-    rec.set_option("s5_pf", 2 if wide >= 2 else 1)                       # wide = 2: the wide variant with operand prefetch two steps ahead
-    rec.set_option("s5_items", 3 if wide == 3 else 1)                    # wide = 3: streamed over three groups per wave (k_spmm5s)
-    n = g["nrec"]
-    if cheb:
-        rec.chebyshev_recur()
-        assert rel_err(rec.mu_n[:, :, :, :n], g["mu_n"]) < RTOL
-    else:
-        rec.recur_b()
-        assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL and rel_err(rec.b2_b[:, :, :, :n], g["b2_b"]) < RTOL
-    rec.close()
-
-
-@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("name", ["Pt2MnGa_nsp4_local_axis", "Pt2MnGa_nsp4_local_axis_hoh"])
-def test_local_axis_batched_block_lanczos(name, wide):
+def test_local_axis_batched_block_lanczos(name):
     """hamiltonian%local_axis = T (recursion.f90:1830-1832): four sites (Mn, Ga, Pt1, Pt2) with four different moment directions,
     every chain in ITS spin frame.  The reference rotates all blocks per site and runs the sites one by one; here all four chains
     go in one call on the global-frame blocks (per-chain on-site l.s term + conjugation of the outputs).  Fixture: the compiled
@@ -298,7 +273,6 @@ def test_local_axis_batched_block_lanczos(name, wide):
     moms = g["mom"].T
     assert len({tuple(np.round(m, 6)) for m in moms}) == 4                 # four inequivalent directions
     rec = make(problem_dict(g), g["irec"], g["lld"], nsp=g["nsp"])
-    rec.set_option("spmm5_wide", wide)
     rec.recur_b_local_axis(g["rot"])
     n = g["nrec"]
     assert rel_err(rec.a_b[:, :, :, :n], g["a_b"]) < RTOL
