@@ -22,12 +22,18 @@
 //     consumed it; one step (1440 matrix cycles) did not cover gathers that miss L2.
 //   * neighbour blocks are wave-uniform: their addresses are SGPR bases, the lane part of every address is one of three
 //     loop-invariant registers, everything else an instruction immediate: no address arithmetic on the vector ALU.
+//   * K packed across neighbour slots: a spin has 9 complex = 18 real inputs per block, 4.5 MFMA k-steps; with one slot per
+//     three steps (4 + 4 + 1 orbitals, the fifth k-step half empty) 10 % of the matrix work multiplied padding.  The schedule of a
+//     group is now ONE STREAM OF ORBITALS -- entry after entry, 9 orbitals each -- cut into triples of steps that take 4, 4 and 2
+//     orbitals (two k-steps, two k-steps, one k-step): a step may end one entry and begin the next (its lanes then gather from two
+//     different neighbour blocks), the operator fragments are stored in stream order, and nothing but the tail is padded.
 // Tried on top of this and not adopted: a wave walking several groups with the next group's first operands requested during the
 // last entry of the current one (the group prologue -- a chain of dependent loads -- then overlaps matrix work): 1.5 % / 4 % / 7 %
 // SLOWER at 2 / 3 / 4 groups per wave; many short one-group workgroups that the hardware dispatcher balances win.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "kernels_valu.hpp"
 #include "kernels_mfma.hpp"
@@ -38,78 +44,121 @@ namespace rsrec {
 #ifndef S5_WG_GROUPS
 #define S5_WG_GROUPS 4   // groups of 8 atoms per workgroup (x 2 spin waves each): 4 -> 512 threads
 #endif
-constexpr int S5_FRAG_PER_PART = 320;                          // doubles: k-pair 0 (128), k-pair 1 (128), single k-step (64)
-constexpr int S5_FRAG_PER_SLOT = 2 * 2 * 2 * S5_FRAG_PER_PART;   // [sigma_out][sigma_in][rows 0..15 | rows 16..19][320]
+// Operator fragments in STREAM ORDER.  The schedule of an operator class is a list of entries (neighbour column, spin part); entry j
+// contributes the orbitals 9 j .. 9 j + 8 of its input spin to the stream.  Triple T of steps covers the stream orbitals
+//   X: 10 T .. +3 (two k-steps: real, imaginary parts)   Y: 10 T + 4 .. +7 (two k-steps)   Z: 10 T + 8, + 9 (ONE k-step: re, im, re, im)
+constexpr int S5_TRIPLE = 640;                                    // doubles per triple: X [rows 0..15: 128 | rows 16..19: 128], Y [128 | 128], Z [64 | 64]
+constexpr int S5_TRIPLE_BYTES = S5_TRIPLE * 8;
+constexpr int S5_HEAD_TRIPLES = 2;                                 // the triples that hold the two extra entries (orbitals 0..17)
+constexpr int S5_HEAD_DOUBLES = 2 * S5_HEAD_TRIPLES * S5_TRIPLE;   // per-chain head of a stream: [sigma_out][2 triples][640]
+constexpr int S5_MAXENT = 2 * S4_MAXSLOTS + 2;                     // diagonal and spin-flip part of every slot + the two extra entries
+constexpr int S5_ENTPAD = 4;                                       // null entries behind the list (operands are requested two steps ahead)
 
 struct Spmm5Operator {
-    double* d_frag = nullptr;    // [set][tau][slot 0..nslots][sigma_out][sigma_in][2][320]
-    int* d_meta = nullptr;       // [set][tau][1 + 2 S4_MAXSLOTS]: count, then entries slot | flip << 8 (flip: input spin = the other spin)
+    double* d_frag = nullptr;    // [set][tau][sigma_out][ntr][640]
+    int* d_meta = nullptr;       // [set][tau][META]: number of steps, number of extra entries (0 / 2), entry codes column | flip << 8
     size_t frag_bytes = 0, meta_bytes = 0;
-    int ntau = 0, nslots = 0, have_o = 0;
-    static constexpr int META = 1 + 2 * S4_MAXSLOTS;
+    int ntau = 0, nslots = 0, have_o = 0, ntr = 0;
+    static constexpr int META = 2 + S5_MAXENT + S5_ENTPAD;
+    struct Entry { const double* blk; int col; int flip; };        // blk == nullptr: null entry (zero fragments, reads the zero block)
+    struct Head { std::vector<double> blk; int flip = 0; bool valid = false; };
+    std::vector<Head> head_main;   // [set][tau]: first regular entry of the schedule (its first two orbitals share triple 1 with the extra entries)
 
     void release() {
         if (d_frag) (void)hipFree(d_frag);
         if (d_meta) (void)hipFree(d_meta);
         d_frag = nullptr; d_meta = nullptr; frag_bytes = meta_bytes = 0;
     }
-    // entry (row ko, column ki) of the padded 40x40 real form: index = 20 sigma + rho.  rho = 4 s + l (k-step s, lane row l):
-    // s = 2 P + e < 4 -> (part e, m = 4 P + l); s = 4 -> l = 0: (re, m = 8), l = 1: (im, m = 8), l = 2, 3: padding -- the two
-    // members of a k-pair are the real and imaginary part of ONE complex element of the vector (CI layout)
+    // row rho (0..19) of an output spin's padded real form: rho = 4 s + l; s < 4 -> (part s & 1, m = 4 (s >> 1) + l); s = 4 -> l = 0: (re, m = 8),
+    // l = 1: (im, m = 8), l = 2, 3: padding.  (The 16x16x4 result register j of lane row l4 is row l4 + 4 j: registers (2 p, 2 p + 1) are the
+    // real and imaginary part of element m = 4 p + l4 -> one 16-byte store in the CI layout.)
     static bool decode20(int rho, int& part, int& m) {
         const int st = rho >> 2, l = rho & 3;
         if (st < 4) { part = st & 1; m = 4 * (st >> 1) + l; return true; }
         if (l < 2) { part = l; m = 8; return true; }
         return false;
     }
-    static double real40(const double* blk, int ko, int ki) {
-        const int so = ko / 20, wo = ko % 20, si = ki / 20, wi = ki % 20;
-        int po, mo, pi, mi;
-        if (!decode20(wo, po, mo) || !decode20(wi, pi, mi)) return 0.0;
+    // real form of a complex block (column-major interleaved): row (spin so, part po, m mo), column (spin si, part pi, m mi)
+    static double hreal(const double* blk, int so, int po, int mo, int si, int pi, int mi) {
         const int ro = 9 * so + mo, ri = 9 * si + mi;
         const double hr = blk[2 * (ro + 18 * ri)], hi = blk[2 * (ro + 18 * ri) + 1];
         if (po == pi) return hr;
         return po == 0 ? -hi : hi;
     }
-    // one complex block (column-major interleaved) -> fragments: A operand of the 16x16x4 MFMA for rows 0..15 (lane (l15 = row,
-    // l4 = k)) and of the 4x4x4 MFMA for rows 16..19 (lane (i + 4 g + 16 k) = A[16 + i][k], same for the 4 blocks g)
-    static void swizzle(const double* blk, double* out) {
-        for (int so = 0; so < 2; ++so)
-            for (int si = 0; si < 2; ++si) {
-                double* o = out + (so * 2 + si) * 2 * S5_FRAG_PER_PART;
-                for (int l = 0; l < 64; ++l) {
-                    const int k = l >> 4;
-                    for (int part = 0; part < 2; ++part) {
-                        const int ko = 20 * so + (part == 0 ? (l & 15) : 16 + (l & 3));
-                        double* q = o + part * S5_FRAG_PER_PART;
-                        for (int p = 0; p < 2; ++p)
-                            for (int e = 0; e < 2; ++e) q[128 * p + 2 * l + e] = real40(blk, ko, 20 * si + 8 * p + 4 * e + k);
-                        q[256 + l] = real40(blk, ko, 20 * si + 16 + k);
+    static int steps_of(int nent) {
+        const int n = 9 * nent, r = n % 10;
+        return 3 * (n / 10) + (r == 0 ? 0 : r <= 4 ? 1 : r <= 8 ? 2 : 3);
+    }
+    // fragments of triples t0 .. t0 + nt - 1 of the stream of `E` for output spin `sig`: A operand of the 16x16x4 MFMA for rows 0..15
+    // (lane (l15 = row, l4 = k)) and of the 4x4x4 MFMA for rows 16..19 (lane (i + 4 g + 16 k) = A[16 + i][k], same for the 4 blocks g);
+    // k-step lane k of X / Y = stream orbital o0 + k (two k-steps: real / imaginary part of the input), of Z = orbital o0 + (k >> 1), part k & 1
+    static void emit_stream(const std::vector<Entry>& E, int sig, int t0, int nt, double* out) {
+        auto value = [&](int o, int pi, int po, int mo) {
+            const int j = o / 9;
+            if (j >= (int)E.size() || !E[j].blk) return 0.0;
+            return hreal(E[j].blk, sig, po, mo, E[j].flip ? 1 - sig : sig, pi, o % 9);
+        };
+        for (int t = t0; t < t0 + nt; ++t) {
+            double* T = out + (size_t)(t - t0) * S5_TRIPLE;
+            for (int K = 0; K < 3; ++K) {
+                const int base = K == 0 ? 0 : K == 1 ? 256 : 512, o0 = 10 * t + (K == 0 ? 0 : K == 1 ? 4 : 8);
+                for (int q = 0; q < 2; ++q)
+                    for (int l = 0; l < 64; ++l) {
+                        const int k = l >> 4, rho = q == 0 ? (l & 15) : 16 + (l & 3);
+                        int po, mo;
+                        const bool row = decode20(rho, po, mo);
+                        if (K < 2) for (int e = 0; e < 2; ++e) T[base + 128 * q + 2 * l + e] = row ? value(o0 + k, e, po, mo) : 0.0;
+                        else T[base + 64 * q + l] = row ? value(o0 + (k >> 1), k & 1, po, mo) : 0.0;
                     }
-                }
             }
+        }
     }
     // General table: blk[(set * ntau + tau) * (nslots + 1) + s] = column-major interleaved 18x18 complex block of operator class tau,
-    // fragment slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes
-    // nothing and is not scheduled).  Schedule: the spin-diagonal part of every block, plus the spin-flip part of blocks that have one.
+    // slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes nothing and is
+    // not scheduled).  Schedule: the two extra entries first (spin-diagonal and spin-flip part; a null entry if the block has no such
+    // part -- the kernel switches from the second input to the first after orbital 18, a step boundary), then the spin-diagonal part
+    // of every block, plus the spin-flip part of the blocks that have one.
     const char* build_custom(int nslots_lat, int ntau_, int nset, const std::vector<const double*>& blk) {
         if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
         ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0;
-        const int nfs = nslots + 1;
-        const size_t per_set = (size_t)ntau * nfs * S5_FRAG_PER_SLOT;
-        std::vector<double> host(per_set * nset, 0.0);
+        const int nfs = nslots + 1, null_col = nslots + 1;
+        std::vector<std::vector<Entry>> sched((size_t)nset * ntau);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
+        head_main.assign((size_t)nset * ntau, Head());
+        int maxent = 0;
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
+                std::vector<Entry>& E = sched[(size_t)set * ntau + tau];
+                const double* const* B = blk.data() + ((size_t)set * ntau + tau) * nfs;
                 int* M = meta.data() + ((size_t)set * ntau + tau) * META;
-                for (int s = 0; s < nfs; ++s) {
-                    const double* src = blk[((size_t)set * ntau + tau) * nfs + s];
-                    if (!src) continue;
-                    swizzle(src, host.data() + set * per_set + ((size_t)tau * nfs + s) * S5_FRAG_PER_SLOT);
-                    M[1 + M[0]] = s; M[0]++;
-                    if (Spmm4Operator::pattern_of(src) == 0) { M[1 + M[0]] = s | (1 << 8); M[0]++; }
+                if (B[nslots]) {
+                    E.push_back({B[nslots], nslots, 0});
+                    E.push_back({Spmm4Operator::pattern_of(B[nslots]) == 0 ? B[nslots] : nullptr, nslots, 1});
+                    M[1] = 2;
                 }
+                for (int s = 0; s < nslots; ++s) {
+                    if (!B[s]) continue;
+                    if ((int)E.size() == M[1]) {
+                        Head& H = head_main[(size_t)set * ntau + tau];
+                        H.blk.assign(B[s], B[s] + 2 * BLK); H.flip = 0; H.valid = true;
+                    }
+                    E.push_back({B[s], s, 0});
+                    if (Spmm4Operator::pattern_of(B[s]) == 0) E.push_back({B[s], s, 1});
+                }
+                M[0] = steps_of((int)E.size());
+                for (int j = 0; j < S5_MAXENT + S5_ENTPAD; ++j)
+                    M[2 + j] = j < (int)E.size() ? ((E[j].blk ? E[j].col : null_col) | (E[j].flip << 8)) : null_col;
+                maxent = std::max(maxent, (int)E.size());
             }
+        ntr = (9 * maxent + 9) / 10 + 1;                       // + one zero triple: the last steps request operands beyond the end
+        const size_t per_sig = (size_t)ntr * S5_TRIPLE, per_set = (size_t)ntau * 2 * per_sig;
+        std::vector<double> host(per_set * nset, 0.0);
+        for (int set = 0; set < nset; ++set)
+            for (int tau = 0; tau < ntau; ++tau)
+                for (int sig = 0; sig < 2; ++sig) {
+                    const std::vector<Entry>& E = sched[(size_t)set * ntau + tau];
+                    emit_stream(E, sig, 0, (9 * (int)E.size() + 9) / 10, host.data() + set * per_set + ((size_t)tau * 2 + sig) * per_sig);
+                }
         const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
         if (need > frag_bytes) {
             if (d_frag) (void)hipFree(d_frag);
@@ -126,6 +175,14 @@ struct Spmm5Operator {
         if (hipMemcpy(d_frag, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 fragments failed";
         if (hipMemcpy(d_meta, meta.data(), mneed, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 schedule failed";
         return nullptr;
+    }
+    // Head of the stream of (set, tau) with `extra` as the block of the extra on-site slot (both spin parts scheduled): the per-chain
+    // fragments of local-axis runs.  out: [sigma_out][2 triples][640]
+    void emit_head(int set, int tau, const double* extra, double* out) const {
+        const Head& H = head_main[(size_t)set * ntau + tau];
+        std::vector<Entry> E = {{extra, nslots, 0}, {extra, nslots, 1}};
+        if (H.valid) E.push_back({H.blk.data(), 0, H.flip});
+        for (int sig = 0; sig < 2; ++sig) emit_stream(E, sig, 0, S5_HEAD_TRIPLES, out + (size_t)sig * S5_HEAD_TRIPLES * S5_TRIPLE);
     }
     // The Hamiltonian itself.  Set 0: the blocks of h (slot 0 carries + l.s when !hoh).  Set 1 (hoh second pass) is built so that
     // ONE SpMM pass over hpsi = h psi plus one extra on-site slot reading psi gives the whole
@@ -158,39 +215,29 @@ struct Spmm5Operator {
             }
         return build_custom(nslots_lat, nt, nset, blk);
     }
-    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * (nslots + 1) * S5_FRAG_PER_SLOT; }
+    const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * 2 * ntr * S5_TRIPLE; }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
 };
 
 typedef double s5_d2 __attribute__((ext_vector_type(2)));
-struct S5Pair { s5_d2 b[9]; s5_d2 a[2]; };      // operands of two k-steps: nine psi tiles; operator rows 0..15 and 16..19
-struct S5Single { double b[9]; double a[2]; };  // the spin's fifth k-step (row m = 8: re, im + padding)
+struct S5Pair { s5_d2 b[9]; s5_d2 a[2]; };      // operands of an X / Y step (two k-steps): nine psi tiles; operator rows 0..15 and 16..19
+struct S5Single { double b[9]; double a[2]; };  // operands of a Z step (one k-step)
 struct S5Acc { double4_t m[9]; double r[9]; };  // per tile: 16x16x4 result (rows 0..15) and 4x4x4 result (rows 16..19)
 
-// wave-uniform addressing state of one neighbour slot
-struct S5Slot {
-    const char* tile[GROUP];   // block of the neighbour of atom t (spin 0 half)
-    const char* base;          // vector the slot reads (the second input for the extra on-site slot)
-    unsigned rem;              // remainder tile: byte offset of this lane's neighbour block (per lane: atom l15 >> 1)
-};
+// addressing state of one schedule entry: byte offsets (from the input vector, spin half included) of the neighbour blocks of the 8 atom
+// tiles (wave-uniform) and of this lane's atom of the remainder tile
+struct S5Ent { unsigned off[GROUP]; unsigned rem; };
 
-template <int P>
-__device__ __forceinline__ void s5_load_pair(S5Pair& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
-                                             unsigned lane_main, unsigned lane_rem, unsigned lane16) {
-#pragma unroll
-    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const s5_d2*>(S.tile[t] + spin_off + lane_main + 1152 * P);
-    o.b[8] = *reinterpret_cast<const s5_d2*>(S.base + spin_off + (S.rem + lane_rem) + 1152 * P);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) o.a[q] = *reinterpret_cast<const s5_d2*>(fb + lane16 + (q * S5_FRAG_PER_PART * 8 + 1024 * P));
-}
-__device__ __forceinline__ void s5_load_single(S5Single& o, const S5Slot& S, unsigned spin_off, const char* __restrict__ fb,
-                                               unsigned lane_single, unsigned lane_rem_single, unsigned lane8) {
-#pragma unroll
-    for (int t = 0; t < GROUP; ++t) o.b[t] = *reinterpret_cast<const double*>(S.tile[t] + spin_off + lane_single);
-    o.b[8] = *reinterpret_cast<const double*>(S.base + spin_off + (S.rem + lane_rem_single));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) o.a[q] = *reinterpret_cast<const double*>(fb + lane8 + (q * S5_FRAG_PER_PART * 8 + 2048));
-}
+// step S (0..26) of a period of 10 entries = 90 stream orbitals = 9 triples
+template <int S> struct S5St {
+    static constexpr int T = S / 3, K = S % 3;
+    static constexpr int W = K == 2 ? 2 : 4;                                  // orbitals of the step
+    static constexpr int o0 = 10 * T + (K == 0 ? 0 : K == 1 ? 4 : 8);
+    static constexpr int eA = o0 / 9, mA0 = o0 % 9, sp = 9 - mA0;             // entry of the first orbital; orbitals >= sp belong to entry eA + 1
+    static constexpr bool straddle = sp < W;
+    static constexpr bool opens = straddle || mA0 == 0;                       // an entry begins in this step:
+    static constexpr int eOpen = mA0 == 0 ? eA : eA + 1;                      //   this one
+};
 
 // issue order: one operand load, then PER MFMAs
 template <int NL, int NM>
@@ -204,7 +251,7 @@ __device__ __forceinline__ void s5_interleave() {
     __builtin_amdgcn_sched_group_barrier(0x8, NM - PER * NL, 0);
 }
 
-__device__ __forceinline__ void s5_mfma_pair(S5Acc& acc, const S5Pair& o) {
+__device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Pair& o) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -212,105 +259,151 @@ __device__ __forceinline__ void s5_mfma_pair(S5Acc& acc, const S5Pair& o) {
             acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0][e], o.b[t][e], acc.m[t], 0, 0, 0);
             acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1][e], o.b[t][e], acc.r[t], 0, 0, 0);
         }
+    s5_interleave<11, 36>();
 }
-__device__ __forceinline__ void s5_mfma_single(S5Acc& acc, const S5Single& o) {
+__device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Single& o) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0], o.b[t], acc.m[t], 0, 0, 0);
         acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1], o.b[t], acc.r[t], 0, 0, 0);
     }
+    s5_interleave<11, 18>();
 }
 
-// All schedule entries of a group for one wave (output spin `sig`).  An entry = (neighbour slot, flip): the wave multiplies
-// the slot's [sig][si] quadrant with input spin si = sig (spin-diagonal part; the only entry of a collinear hopping block)
-// or si = 1 - sig (spin-flip part of the spin-orbit / non-collinear blocks).  Three steps per entry -- k-pair 0 (X), k-pair 1 (Y),
-// single k-step (Z) -- with the operands requested TWO steps ahead: while X runs, Y (issued one step ago) and Z (issued now) are
-// in flight; a register set is reloaded right after the step that consumed it.
-// TWO: slot id `nslots` (one past the lattice's slots) is the extra on-site slot; it reads the second input vector in2b (hoh second
-// pass, recursion.f90:1543: the (e_nu + l.s) term acts on psi itself; local-axis runs: the per-chain on-site term) and, if
-// fr_extra is given, takes its fragments from that per-chain table.
+template <int N> using S5C = std::integral_constant<int, N>;
+#define S5_GLOBAL __attribute__((address_space(1)))
+typedef const S5_GLOBAL char* s5_gp;      // explicit global address space: the loads stay global_load behind the scalar-base barriers below
+
+// The whole stream of a group for one wave (output spin `sig`).  Operands are requested TWO steps ahead into three register sets
+// (X, Y: two k-steps; Z: one): while step s runs, the operands of s + 1 are in flight and those of s + 2 are issued into the set that
+// step s - 1 consumed.  The step pattern repeats after 10 entries (27 steps), so which steps end one entry and begin the next, and at
+// which orbital, is static: such a step selects per lane between the neighbour blocks of two entries, every other step addresses its
+// blocks through wave-uniform bases.  An entry's neighbour indices are scalar loads issued when the entry before it is opened.
+// TWO: the first two entries (18 orbitals = steps 0..4 of the first period) are the extra on-site slot; they read the second input
+// vector in2b (hoh second pass, recursion.f90:1543: the (e_nu + l.s) term acts on psi itself; local-axis runs: the per-chain on-site
+// term), and if fr_head is given the first two triples of fragments come from that per-chain table.
 template <bool TWO>
-__device__ __forceinline__ void s5_run_slots(S5Acc& acc, const int* __restrict__ share, const double* __restrict__ fr, const double* __restrict__ fr_extra,
-                                             const char* __restrict__ inb, const char* __restrict__ in2b,
-                                             const int* __restrict__ nbr5 /*(kk+1) x (nslots+1): absent -> zero block, last column = self*/,
-                                             const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: (nslots+1) * atom of the remainder column*/,
-                                             int nslots, int sig,
-                                             unsigned lane_main, unsigned lane_single, unsigned lane_rem, unsigned lane_rem_single, unsigned lane16, unsigned lane8) {
-    const int nmine = share[0];
-    if (nmine <= 0) return;
-    const int nstride = nslots + 1;
-    // neighbour indices: wave-uniform scalar loads for the 8 atom tiles, one per-lane load for the remainder tile
-    auto load_idx = [&](int s, int (&n)[GROUP], int& nr) {
+__device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict__ meta, const char* __restrict__ fr, const char* __restrict__ fr_head,
+                                              const char* __restrict__ inb, const char* __restrict__ in2b,
+                                              const int* __restrict__ nbr5 /*(kk+1) x ncol: absent -> zero block, column nslots = self, nslots + 1 = zero block*/,
+                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: ncol * atom of the remainder column*/,
+                                              int ncol, int sig, int l4,
+                                              unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8) {
+    int left = meta[0];
+    if (left <= 0) return;
+    const bool extras = TWO && meta[1] != 0;
+    const int* __restrict__ codes = meta + 2;
+    S5Ent E0, E1;
+    int raw[GROUP], rawrem;
+    int code_cur = codes[0], code_nxt = codes[1];
+    auto load_idx = [&](int col) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) n[t] = nbr5[(size_t)nstride * atom[t] + s];
-        nr = nbr5[rem_row + (unsigned)s];
+        for (int t = 0; t < GROUP; ++t) raw[t] = nbr5[(size_t)ncol * atom[t] + col];
+        rawrem = nbr5[rem_row + (unsigned)col];
     };
-    auto make_slot = [&](const int (&n)[GROUP], int nr, S5Slot& S, int s) {
-        const char* base = (TWO && s == nslots) ? in2b : inb;
+    load_idx(code_cur & 255);
+    int ebase = 0, tbase = 0;
+    bool first = true;
+    // entry j (its indices are in raw, its code in code_cur) becomes addressable; the indices of entry j + 1 are requested
+    auto open_entry = [&](int j, S5Ent& E) {
+        const unsigned so = 2592u * (unsigned)((code_cur >> 8) ? 1 - sig : sig);
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) S.tile[t] = base + (size_t)n[t] * (BLD * 8);
-        S.base = base;
-        S.rem = (unsigned)nr * (BLD * 8u);
+        for (int t = 0; t < GROUP; ++t) E.off[t] = (unsigned)raw[t] * (BLD * 8u) + so;
+        E.rem = (unsigned)rawrem * (BLD * 8u) + so;
+        code_cur = code_nxt;
+        code_nxt = codes[j + 2];
+        load_idx(code_cur & 255);
     };
-    const double* __restrict__ fr_sig = fr + (size_t)sig * (2 * 2 * S5_FRAG_PER_PART);
-    const double* __restrict__ fx_sig = (TWO && fr_extra) ? fr_extra + (size_t)sig * (2 * 2 * S5_FRAG_PER_PART) - (size_t)nslots * S5_FRAG_PER_SLOT : fr_sig;
-    auto frag_of = [&](int s, int si) {
-        const double* __restrict__ base = (TWO && s == nslots) ? fx_sig : fr_sig;
-        return reinterpret_cast<const char*>(base + (size_t)s * S5_FRAG_PER_SLOT + si * (2 * S5_FRAG_PER_PART));
+    auto issue = [&](auto s2c, auto& o) {
+        constexpr int S2 = decltype(s2c)::value, S = S2 % 27, wrap = S2 / 27;
+        using I = S5St<S>;
+        S5Ent& EA = (I::eA & 1) ? E1 : E0;
+        S5Ent& EB = (I::eA & 1) ? E0 : E1;
+        if constexpr (I::opens) open_entry(ebase + 10 * wrap + I::eOpen, (I::eOpen & 1) ? E1 : E0);
+        const bool head = wrap == 0 && first && extras;
+        const char* __restrict__ base = (TWO && S < 5 && head) ? in2b : inb;
+        const char* fb = ((TWO && I::T < S5_HEAD_TRIPLES && head && fr_head) ? fr_head + I::T * S5_TRIPLE_BYTES
+                                                                                         : fr + (size_t)(tbase + 9 * wrap + I::T) * S5_TRIPLE_BYTES)
+                                      + (I::K == 0 ? 0 : I::K == 1 ? 2048 : 4096);
+        s5_gp fbg = (s5_gp)fb;
+        asm("" : "+s"(fbg));
+        constexpr unsigned rowA = 288u * I::mA0, rowB = 0u - 288u * I::sp;
+        unsigned lm = I::K < 2 ? lane_main : lane_z, lf = I::K < 2 ? lane16 : lane8;
+        const unsigned lr = I::K < 2 ? lane_rem : lane_rem_z;
+        // the lane parts as values defined in this step's block: instruction selection then folds base (SGPR pair) + lane (32-bit VGPR) +
+        // immediate into the load (a zero-extension hoisted out of the loop made every address a 64-bit vector add)
+        asm volatile("" : "+v"(lm));
+        asm volatile("" : "+v"(lf));
+        using V = std::remove_reference_t<decltype(o.b[0])>;
+        if constexpr (!I::straddle) {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                s5_gp pt = (s5_gp)base + EA.off[t];
+                asm("" : "+s"(pt));            // a wave-uniform base for the load's scalar address operand (not re-associated into a vector add)
+                o.b[t] = *(const S5_GLOBAL V*)(pt + lm + rowA);
+            }
+            o.b[8] = *(const S5_GLOBAL V*)((s5_gp)base + (EA.rem + lr) + rowA);
+        } else {
+            const bool inB = (I::K < 2 ? l4 : (l4 >> 1)) >= I::sp;
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) {
+                const unsigned off = (inB ? EB.off[t] + rowB : EA.off[t] + rowA) + lm;
+                o.b[t] = *(const S5_GLOBAL V*)((s5_gp)base + off);
+            }
+            const unsigned off = (inB ? EB.rem + rowB : EA.rem + rowA) + lr;
+            o.b[8] = *(const S5_GLOBAL V*)((s5_gp)base + off);
+        }
+        if constexpr (I::K < 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) o.a[q] = *(const S5_GLOBAL V*)(fbg + lf + q * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) o.a[q] = *(const S5_GLOBAL V*)(fbg + lf + q * 512);
+        }
     };
-    auto spin_of = [&](int e) { return (e >> 8) ? 1 - sig : sig; };
-    constexpr int NL = 11, NM_PAIR = 36, NM_SINGLE = 18;     // operand loads / MFMA instructions per step, for the issue interleave
-    S5Slot cur;
-    int nraw[GROUP], nrem;
-    int e_cur = share[1];
-    int e_nxt = share[1 + ((1 < nmine) ? 1 : 0)];
-    load_idx(e_cur & 255, nraw, nrem);
-    make_slot(nraw, nrem, cur, e_cur & 255);
     S5Pair X, Y;
     S5Single Z;
-    s5_load_pair<0>(X, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
-    s5_load_pair<1>(Y, cur, 2592u * spin_of(e_cur), frag_of(e_cur & 255, spin_of(e_cur)), lane_main, lane_rem, lane16);
-    for (int j = 0; j < nmine; ++j) {
-        const int e_nxt2 = share[1 + ((j + 2 < nmine) ? j + 2 : 0)];   // the last entry prefetches the first again (discarded): no tail branch
-        load_idx(e_nxt & 255, nraw, nrem);
-        const int si = spin_of(e_cur);
-        s5_load_single(Z, cur, 2592u * si, frag_of(e_cur & 255, si), lane_single, lane_rem_single, lane8);     // Z(e): the last load of this entry
-        s5_mfma_pair(acc, X);
-        s5_interleave<NL, NM_PAIR>();
-        __builtin_amdgcn_sched_barrier(0);
-        make_slot(nraw, nrem, cur, e_nxt & 255);        // every load of the current entry has been issued: reuse its addressing state
-        s5_load_pair<0>(X, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
-        s5_mfma_pair(acc, Y);
-        s5_interleave<NL, NM_PAIR>();
-        __builtin_amdgcn_sched_barrier(0);
-        s5_load_pair<1>(Y, cur, 2592u * spin_of(e_nxt), frag_of(e_nxt & 255, spin_of(e_nxt)), lane_main, lane_rem, lane16);
-        s5_mfma_single(acc, Z);
-        s5_interleave<NL, NM_SINGLE>();
-        __builtin_amdgcn_sched_barrier(0);
-        e_cur = e_nxt;
-        e_nxt = e_nxt2;
+    issue(S5C<0>{}, X);
+    issue(S5C<1>{}, Y);
+#define S5_STEP(S, NEXT, CUR)                 \
+    if (left > (S)) {                         \
+        issue(S5C<(S) + 2>{}, NEXT);          \
+        s5_mfma(acc, CUR);                    \
+        __builtin_amdgcn_sched_barrier(0);    \
     }
+    for (;; left -= 27) {
+        S5_STEP(0, Z, X) S5_STEP(1, X, Y) S5_STEP(2, Y, Z) S5_STEP(3, Z, X) S5_STEP(4, X, Y) S5_STEP(5, Y, Z)
+        S5_STEP(6, Z, X) S5_STEP(7, X, Y) S5_STEP(8, Y, Z) S5_STEP(9, Z, X) S5_STEP(10, X, Y) S5_STEP(11, Y, Z)
+        S5_STEP(12, Z, X) S5_STEP(13, X, Y) S5_STEP(14, Y, Z) S5_STEP(15, Z, X) S5_STEP(16, X, Y) S5_STEP(17, Y, Z)
+        S5_STEP(18, Z, X) S5_STEP(19, X, Y) S5_STEP(20, Y, Z) S5_STEP(21, Z, X) S5_STEP(22, X, Y) S5_STEP(23, Y, Z)
+        S5_STEP(24, Z, X) S5_STEP(25, X, Y) S5_STEP(26, Y, Z)
+        if (left <= 27) break;
+        ebase += 10; tbase += 9; first = false;
+    }
+#undef S5_STEP
 }
 
 // One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
 // different spin) land on the same SIMD.  Input and output vectors in the CI layout.
 template <bool TWO>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
-                                               const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+1), absent -> kk, last column = self*/,
-                                               const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta,
+                                               const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+2)*/,
+                                               const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta, int ntr,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
                                                const double* __restrict__ in2_all = nullptr,
-                                               const double* __restrict__ frag_extra = nullptr /*[chain][tau][S5_FRAG_PER_SLOT]: per-chain extra-slot operator*/,
+                                               const double* __restrict__ frag_head = nullptr /*[chain][tau][S5_HEAD_DOUBLES]: per-chain head of the stream*/,
                                                int ntau = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // CI layout (kernels_mfma.hpp): element (r, c) of a block = complex at doubles 36 r + 2 c; row r = 9 sigma + m.  k-pair P of
-    // input spin sigma = rows m = 4 P + l4 (re, im = the pair's two k-steps); single k-step = row m = 8 (lane row 0: re, 1: im)
-    const unsigned lane_main = 8u * (36 * l4 + 2 * l15), lane_single = 8u * (288 + 2 * l15 + (l4 & 1));
-    const unsigned lane_rem = 8u * (36 * l4 + 32 + 2 * (l15 & 1)), lane_rem_single = 8u * (288 + 32 + 2 * (l15 & 1) + (l4 & 1));
+    // CI layout (kernels_mfma.hpp): element (r, c) of a block = complex at doubles 36 r + 2 c; row r = 9 sigma + m.  Lane (l15, l4) of an
+    // X / Y step reads element (m0 + l4, c = l15) as one 16-byte load (re, im = the step's two k-steps); of a Z step element
+    // (m0 + (l4 >> 1), l15), part l4 & 1.  m0 (and the entry) are per-step constants of the stream (S5St).
+    const unsigned lane_main = 8u * (36 * l4 + 2 * l15), lane_z = 8u * (36 * (l4 >> 1) + 2 * l15 + (l4 & 1));
+    const unsigned lane_rem = 8u * (36 * l4 + 32 + 2 * (l15 & 1)), lane_rem_z = 8u * (36 * (l4 >> 1) + 32 + 2 * (l15 & 1) + (l4 & 1));
     const unsigned lane16 = 16u * lane, lane8 = 8u * lane;
+    const int ncol = D.nslots + 2;
     // grid.y may be smaller than the number of chains ("chain_fold"): a workgroup then serves chains blockIdx.y, + gridDim.y, ...
 #pragma unroll 1
     for (int chain = blockIdx.y; chain < D.nchains; chain += gridDim.y) {
@@ -341,23 +434,23 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     }
     for (; g < gend; g += gstep) {
         const int* __restrict__ grp = order + (size_t)g * GROUP;
-        int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the slot loop
+        int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the step loop
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; atom[t] = a >= 0 ? a : zero_block; }
         const int first = atom[0];
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
         int my_rem_atom = grp[l15 >> 1];
         my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
-        const unsigned rem_row = (unsigned)(D.nslots + 1) * (unsigned)my_rem_atom;
+        const unsigned rem_row = (unsigned)ncol * (unsigned)my_rem_atom;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
-        const double* __restrict__ fr = frag + (size_t)tau * (D.nslots + 1) * S5_FRAG_PER_SLOT;
-        const double* __restrict__ fx = (TWO && frag_extra) ? frag_extra + ((size_t)chain * ntau + tau) * S5_FRAG_PER_SLOT : nullptr;
+        const char* __restrict__ fr = reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);
+        const char* __restrict__ fh = (TWO && frag_head) ? reinterpret_cast<const char*>(frag_head + ((size_t)chain * ntau + tau) * S5_HEAD_DOUBLES + (size_t)sig * S5_HEAD_TRIPLES * S5_TRIPLE) : nullptr;
 
         S5Acc acc;
 #pragma unroll
         for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
 
-        s5_run_slots<TWO>(acc, M, fr, fx, inb, in2b, nbr, atom, rem_row, D.nslots, sig, lane_main, lane_single, lane_rem, lane_rem_single, lane16, lane8);
+        s5_run_stream<TWO>(acc, M, fr, fh, inb, in2b, nbr, atom, rem_row, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI

@@ -74,7 +74,7 @@ struct rsrec_handle {
     std::vector<int> nbr;        // [kk][nslots] 0-based, -1 absent, slot 0 = self
     std::vector<int> iz0;        // 0-based types
     std::vector<int> radj_ptr, radj;  // reverse adjacency: atoms whose neighbour list contains n
-    DevBuf d_nbr, d_iz, d_nbr5;   // nbr5: (kk+1) x nslots, absent neighbours and the extra row point at the zero block (k_spmm5)
+    DevBuf d_nbr, d_iz, d_nbr5;   // nbr5: (kk+1) x (nslots+2), absent neighbours and the extra row point at the zero block (k_spmm5)
     // hamiltonian
     int hslots = 0, hoh = 0, nsp = 2;
     DevBuf d_hst, d_hloc, d_host, d_holoc, d_enim, d_lsham;
@@ -418,11 +418,12 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
     HIPCK(h, hipMemcpy(h->d_nbr.p, h->nbr.data(), h->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_iz.p, h->iz0.data(), (size_t)kk * sizeof(int), hipMemcpyHostToDevice));
     {
-        // (kk+1) x (nslots+1): absent neighbours and the extra row -> zero block; last column = the atom itself (extra on-site slot)
-        std::vector<int> n5((size_t)(kk + 1) * (nslots + 1), kk);
+        // (kk+1) x (nslots+2): absent neighbours and the extra row -> zero block; column nslots = the atom itself (extra on-site slot),
+        // column nslots + 1 = zero block (null entries of the k_spmm5 schedule)
+        std::vector<int> n5((size_t)(kk + 1) * (nslots + 2), kk);
         for (int i = 0; i < kk; ++i) {
-            for (int j = 0; j < nslots; ++j) { const int n = h->nbr[(size_t)i * nslots + j]; if (n >= 0) n5[(size_t)i * (nslots + 1) + j] = n; }
-            n5[(size_t)i * (nslots + 1) + nslots] = i;
+            for (int j = 0; j < nslots; ++j) { const int n = h->nbr[(size_t)i * nslots + j]; if (n >= 0) n5[(size_t)i * (nslots + 2) + j] = n; }
+            n5[(size_t)i * (nslots + 2) + nslots] = i;
         }
         HIPCK(h, h->d_nbr5.reserve(n5.size() * sizeof(int)));
         HIPCK(h, hipMemcpy(h->d_nbr5.p, n5.data(), n5.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -768,7 +769,7 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
-    k_spmm5<TWO><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), in, out, in2, extra, ntau);
+    k_spmm5<TWO><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau);
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
@@ -804,7 +805,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     if (rot && !MFMA) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set (option kernels = 0 or 2)");
     const int ntau = h->nmax + h->ntype;
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
-    const int la_fps = S5_FRAG_PER_SLOT;
+    const int la_fps = S5_HEAD_DOUBLES;
     if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * la_fps * sizeof(double)));
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
@@ -891,7 +892,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                             E[2 * (i + NB * j)] = sr; E[2 * (i + NB * j) + 1] = si;
                         }
                     if (hoh) for (int e = 0; e < 2 * BLK; ++e) E[e] += h->host_enim[2 * (size_t)BLK * ty + e];
-                    Spmm5Operator::swizzle(E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
+                    OP.emit_head(hoh ? 1 : 0, tau, E.data(), fr.data() + ((size_t)c * ntau + tau) * la_fps);
                 }
             }
             XFER(xfer_h2d(h, h->d_la_extra.p, fr.data(), fr.size() * sizeof(double)));
