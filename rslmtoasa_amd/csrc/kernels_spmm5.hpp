@@ -272,6 +272,7 @@ __device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Single& o) {
 
 template <int N> using S5C = std::integral_constant<int, N>;
 #define S5_GLOBAL __attribute__((address_space(1)))
+#define S5_CONST __attribute__((address_space(4)))
 typedef const S5_GLOBAL char* s5_gp;      // explicit global address space: the loads stay global_load behind the scalar-base barriers below
 
 // The whole stream of a group for one wave (output spin `sig`).  Operands are requested TWO steps ahead into three register sets
@@ -286,20 +287,22 @@ template <bool TWO>
 __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict__ meta, const char* __restrict__ fr, const char* __restrict__ fr_head,
                                               const char* __restrict__ inb, const char* __restrict__ in2b,
                                               const int* __restrict__ nbr5 /*(kk+1) x ncol: absent -> zero block, column nslots = self, nslots + 1 = zero block*/,
-                                              const int (&atom)[GROUP] /*padding -> zero block*/, unsigned rem_row /*per lane: ncol * atom of the remainder column*/,
+                                              const int (&atom)[GROUP] /*padding -> zero block*/, int rem_sel /*per lane: tile (atom of the group) of its remainder column*/,
                                               int ncol, int sig, int l4,
                                               unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8) {
     int left = meta[0];
     if (left <= 0) return;
     const bool extras = TWO && meta[1] != 0;
-    const int* __restrict__ codes = meta + 2;
+    // the schedule and the neighbour table through the constant address space: scalar loads (a vector load + readfirstlane here put a
+    // vmcnt wait on an old load into the step loop, which also drained the operand loads issued after it)
+    const S5_CONST int* codes = (const S5_CONST int*)(meta + 2);
+    const S5_CONST int* nbr = (const S5_CONST int*)nbr5;
     S5Ent E0, E1;
-    int raw[GROUP], rawrem;
+    int raw[GROUP];
     int code_cur = codes[0], code_nxt = codes[1];
     auto load_idx = [&](int col) {
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) raw[t] = nbr5[(size_t)ncol * atom[t] + col];
-        rawrem = nbr5[rem_row + (unsigned)col];
+        for (int t = 0; t < GROUP; ++t) raw[t] = nbr[(size_t)ncol * atom[t] + col];
     };
     load_idx(code_cur & 255);
     int ebase = 0, tbase = 0;
@@ -309,7 +312,10 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
         const unsigned so = 2592u * (unsigned)((code_cur >> 8) ? 1 - sig : sig);
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) E.off[t] = (unsigned)raw[t] * (BLD * 8u) + so;
-        E.rem = (unsigned)rawrem * (BLD * 8u) + so;
+        // remainder tile: this lane's atom is tile rem_sel = l15 >> 1 of the group -- selected from the scalar indices
+        const int r01 = (rem_sel & 1) ? raw[1] : raw[0], r23 = (rem_sel & 1) ? raw[3] : raw[2], r45 = (rem_sel & 1) ? raw[5] : raw[4], r67 = (rem_sel & 1) ? raw[7] : raw[6];
+        const int r03 = (rem_sel & 2) ? r23 : r01, r47 = (rem_sel & 2) ? r67 : r45;
+        E.rem = (unsigned)((rem_sel & 4) ? r47 : r03) * (BLD * 8u) + so;
         code_cur = code_nxt;
         code_nxt = codes[j + 2];
         load_idx(code_cur & 255);
@@ -441,7 +447,6 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
         int my_rem_atom = grp[l15 >> 1];
         my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
-        const unsigned rem_row = (unsigned)ncol * (unsigned)my_rem_atom;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
         const char* __restrict__ fr = reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);
         const char* __restrict__ fh = (TWO && frag_head) ? reinterpret_cast<const char*>(frag_head + ((size_t)chain * ntau + tau) * S5_HEAD_DOUBLES + (size_t)sig * S5_HEAD_TRIPLES * S5_TRIPLE) : nullptr;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #pragma unroll
         for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
 
-        s5_run_stream<TWO>(acc, M, fr, fh, inb, in2b, nbr, atom, rem_row, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
+        s5_run_stream<TWO>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI
