@@ -27,6 +27,13 @@
 //     group is now ONE STREAM OF ORBITALS -- entry after entry, 9 orbitals each -- cut into triples of steps that take 4, 4 and 2
 //     orbitals (two k-steps, two k-steps, one k-step): a step may end one entry and begin the next (its lanes then gather from two
 //     different neighbour blocks), the operator fragments are stored in stream order, and nothing but the tail is padded.
+//     (-10 % matrix instructions; measured 4.90 -> 4.65 ms per level on 64 x 22^3, spin-mixing stencil 9.0 -> 8.1 ms.)  The step
+//     pattern repeats after 10 entries = 27 steps and is unrolled statically; the steps of the tail are skipped one by one.
+//     Control-flow forms of that unrolled period that were tried: one exit per step / per triple (also with a private copy of the
+//     result stores per exit), the whole period as one block with the tail in a second copy, a wave-uniform switch over nine static
+//     triples -- all made the register allocator spill accumulator tuples; a run-time triple (entry boundaries as scalar state,
+//     per-lane block select in every step) kept its registers but paid 3 vector-ALU instructions per tile and step: 4.99 ms.
+//     The skippable steps cost exactness of the compiler's vmcnt waits at the joins (it has to assume the shortest path).
 // Tried on top of this and not adopted: a wave walking several groups with the next group's first operands requested during the
 // last entry of the current one (the group prologue -- a chain of dependent loads -- then overlaps matrix work): 1.5 % / 4 % / 7 %
 // SLOWER at 2 / 3 / 4 groups per wave; many short one-group workgroups that the hardware dispatcher balances win.
