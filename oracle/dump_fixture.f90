@@ -1,4 +1,4 @@
-! TEST INFRASTRUCTURE ONLY (oracle) -- compiled only in the build container, never shipped.
+! TEST INFRASTRUCTURE ONLY (oracle) -- compiled and run only in the build container (the fixtures it writes are committed).
 !
 ! Fixture generator: links against the *compiled reference modules* (oracle/_ref/librslmto_ref.a,
 ! built by oracle/build_ref.sh from the sources where they lie) and replays the reference's own

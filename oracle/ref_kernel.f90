@@ -1,4 +1,6 @@
-! TEST INFRASTRUCTURE ONLY (oracle) -- compiled only in the build container, never shipped.
+! TEST INFRASTRUCTURE ONLY (oracle) -- compiled only in the build container.  The binary (oracle/_ref/ref_kernel.x) travels to the
+! GPU box as the CPU leg of bench.py (cpu_baseline.kind = "reference") and as a checker of the -m gpu tests; nothing under
+! rslmtoasa_amd/ uses it.
 !
 ! Reference-kernel driver: feeds a recursion problem (lattice tables + Hamiltonian blocks read from
 ! `kernel_in.bin`, written by oracle/fixture_io.py) straight into the *compiled reference*

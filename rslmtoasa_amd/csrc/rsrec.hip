@@ -372,6 +372,14 @@ extern "C" void rsrec_site_partition(int rank, int nprocs, int nsites, int* star
     *end_atom = start + per - 1;
 }
 
+// cached regions (device order lists) of lattice epochs that ended; the stream is idle between calls
+static void release_regions(rsrec_t* h) {
+    if (!h->region_cache.empty()) (void)hipDeviceSynchronize();
+    for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
+    h->region_cache.clear();
+    h->cur_order = nullptr; h->cur_cum = nullptr;
+}
+
 extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* nn, const int32_t* iz, int nmax, int ntype) {
     if (!h || !nn || !iz || kk <= 0 || nncols < 1 || nmax < 0 || nmax > kk || ntype < 1) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: bad argument");
     HIPCK(h, hipSetDevice(h->device));
@@ -381,6 +389,7 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
         h->lat_nn.size() == (size_t)kk * nncols && std::memcmp(h->lat_nn.data(), nn, h->lat_nn.size() * sizeof(int32_t)) == 0 &&
         std::memcmp(h->lat_iz.data(), iz, (size_t)kk * sizeof(int32_t)) == 0)
         return RSREC_OK;
+    // validate and convert into local tables first: a refused call leaves the handle as it was
     int nslots = 1;
     for (int i = 0; i < kk; ++i) {
         const int nr = nn[i];
@@ -388,22 +397,28 @@ extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* 
         nslots = std::max(nslots, nr);
         if (iz[i] < 1 || iz[i] > ntype) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: iz(%d)=%d outside 1..%d", i + 1, iz[i], ntype);
     }
-    h->kk = kk; h->nslots = nslots; h->nmax = nmax; h->ntype = ntype;
-    h->nbr.assign((size_t)kk * nslots, -1);
-    h->iz0.resize(kk);
-    std::vector<int> deg(kk + 1, 0);
+    std::vector<int> nbr_new((size_t)kk * nslots, -1), iz_new(kk), deg(kk + 1, 0);
     for (int i = 0; i < kk; ++i) {
-        h->iz0[i] = iz[i] - 1;
-        h->nbr[(size_t)i * nslots] = i;
+        iz_new[i] = iz[i] - 1;
+        nbr_new[(size_t)i * nslots] = i;
         const int nr = nn[i];
         for (int j = 1; j < nr; ++j) {   // slots 2..nn(i,1) of the reference (recursion.f90:1614)
             const int n = nn[(size_t)i + (size_t)kk * j];
             if (n == 0) continue;
             if (n < 0 || n > kk) return fail(h, RSREC_ERR_ARG, "rsrec_set_lattice: nn(%d,%d)=%d outside 0..%d", i + 1, j + 1, n, kk);
-            h->nbr[(size_t)i * nslots + j] = n - 1;
+            nbr_new[(size_t)i * nslots + j] = n - 1;
             deg[n - 1]++;
         }
     }
+    // from here on the handle changes: until the last table is uploaded it holds no lattice (a failed upload must not leave the
+    // unchanged-lattice shortcut above pointing at half-replaced tables), and the cached regions of the old lattice are released
+    h->have_lattice = false;
+    h->have_ham = false;
+    h->lat_nn.clear(); h->lat_iz.clear();
+    release_regions(h);
+    h->kk = kk; h->nslots = nslots; h->nmax = nmax; h->ntype = ntype;
+    h->nbr.swap(nbr_new);
+    h->iz0.swap(iz_new);
     h->radj_ptr.assign(kk + 1, 0);
     for (int n = 0; n < kk; ++n) h->radj_ptr[n + 1] = h->radj_ptr[n] + deg[n];
     h->radj.resize(h->radj_ptr[kk]);
@@ -456,7 +471,8 @@ extern "C" int rsrec_set_positions(rsrec_t* h, const double* cr) {
         for (int a = 0; a < 3; ++a) q[a] = (unsigned)std::min(1023.0, std::max(0.0, (cr[3 * (size_t)i + a] - lo[a]) / span * 1023.0));
         h->spatial_key[i] = morton3(q[0], q[1], q[2]);
     }
-    h->lattice_epoch++;        // cached region orders were built with the old keys
+    h->lattice_epoch++;        // cached region orders were built with the old keys: they can never match again
+    release_regions(h);
     return RSREC_OK;
 }
 

@@ -262,6 +262,28 @@ def test_errors_are_loud():
     rec.close()
 
 
+def test_refused_lattice_leaves_the_engine_usable():
+    """rsrec_set_lattice validates before it touches the handle: after a refused table the old lattice still answers, bit for bit."""
+    from rslmtoasa_amd._lib import ERR_ARG, RsrecError
+    g = load_golden("bccFe_nsp2_block")
+    rec = make(problem_dict(g), g["irec"], g["lld"])
+    rec.recur_b()
+    a0, b0 = rec.a_b.copy(), rec.b2_b.copy()
+    good = rec.lattice.nn
+    bad = np.array(good, copy=True, order="F")
+    bad[bad.shape[0] // 2, 2] = bad.shape[0] + 7             # a neighbour index outside the cluster, found after half the rows were converted
+    rec.lattice.nn = bad
+    with pytest.raises(RsrecError) as ei:
+        rec.update_lattice()
+    assert ei.value.code == ERR_ARG and "outside" in str(ei.value)
+    rec.lattice.nn = good
+    rec.update_lattice()
+    rec.restore_to_default()
+    rec.recur_b()
+    assert np.array_equal(rec.a_b, a0) and np.array_equal(rec.b2_b, b0)
+    rec.close()
+
+
 @pytest.mark.parametrize("name", ["Pt2MnGa_nsp4_local_axis", "Pt2MnGa_nsp4_local_axis_hoh"])
 def test_local_axis_batched_block_lanczos(name):
     """hamiltonian%local_axis = T (recursion.f90:1830-1832): four sites (Mn, Ga, Pt1, Pt2) with four different moment directions,
