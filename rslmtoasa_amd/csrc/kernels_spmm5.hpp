@@ -33,7 +33,9 @@
 //     result stores per exit), the whole period as one block with the tail in a second copy, a wave-uniform switch over nine static
 //     triples -- all made the register allocator spill accumulator tuples; a run-time triple (entry boundaries as scalar state,
 //     per-lane block select in every step) kept its registers but paid 3 vector-ALU instructions per tile and step: 4.99 ms.
-//     The skippable steps cost exactness of the compiler's vmcnt waits at the joins (it has to assume the shortest path).
+//     The skippable steps cost exactness of the compiler's vmcnt waits at the joins (it has to assume the shortest path).  An
+//     all-pair stream (steps of 4 orbitals only, period 4 entries = 9 steps that can run without branches) needs a third two-k-step
+//     operand set: 18 registers over the 256 of a wave at two waves per SIMD.
 // Tried on top of this and not adopted: a wave walking several groups with the next group's first operands requested during the
 // last entry of the current one (the group prologue -- a chain of dependent loads -- then overlaps matrix work): 1.5 % / 4 % / 7 %
 // SLOWER at 2 / 3 / 4 groups per wave; many short one-group workgroups that the hardware dispatcher balances win.
