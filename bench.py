@@ -327,7 +327,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    tm_acc = {"hop_ms": 0.0, "hop_launches": 0.0, "atom_steps": 0.0, "block_multiplies": 0.0, "total_ms": 0.0, "host_ms": 0.0}
+    tm_acc = {"hop_ms": 0.0, "hop_launches": 0.0, "atom_steps": 0.0, "block_multiplies": 0.0, "total_ms": 0.0, "host_ms": 0.0, "hop_mfma_flop": 0.0}
     for _ in range(args.steps):
         step()
         tm = rec.timing()
@@ -360,6 +360,7 @@ def main():
         hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + (tm_acc["atom_steps"] if fuses else 0.0))
         hop_s = tm_acc["hop_ms"] * 1e-3
         achieved = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
+        executed = tm_acc["hop_mfma_flop"] / hop_s * 1e-12 if hop_s > 0 else 0.0   # matrix flops the kernel issued (tile padding included)
         step_tflops = flop_total / world / elapsed * 1e-12          # per-GPU whole-level rate
         kernel = "k_spmm5"
         traffic, traffic_src = (None, None) if tuned else profiled_traffic(wl_key, kernel)
@@ -394,7 +395,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel + " (H|psi> block SpMM, FP64 MFMA)" if not fuses else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
-                         "flops_counted": "nominal 46656 per block multiply incl. structural zeros of spin-diagonal blocks" if not args.spin_mixing else "nominal 46656 per block multiply; spin-mixing blocks: nothing skipped",
+                         "flops_counted": ("algorithmic = 46656 per block multiply (SURVEY 8d: the reference's zgemm on full 18x18 blocks), structural zeros of "
+                                           "spin-diagonal blocks included -- the kernel skips them, so this rate can exceed the pipe's peak") if not args.spin_mixing else
+                                          "algorithmic = 46656 per block multiply; spin-mixing blocks: nothing skipped",
+                         # what the matrix pipe actually did: MFMA flops issued by the kernel (18 -> 20 row padding of the tiles included)
+                         "executed": {"achieved": executed, "frac": executed / FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "executed_per_algorithmic": tm_acc["hop_mfma_flop"] / hop_flop if hop_flop > 0 else None},
                          "hbm_view": {"achieved": bytes_total / world / elapsed * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_total / world / elapsed * 1e-9 / HBM_PEAK_GBS,
                                       "note": "whole recursion level per GPU, algorithmic %d B per atom-step" % BYTES_PER_ATOM_STEP[args.recur]}},
         }

@@ -214,7 +214,9 @@ int rsrec_set_option(rsrec_t *h, const char *key, long value);
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,
  *   out[3] atom-steps processed (sum over chains and steps of active atoms), out[4] block multiplies in H|psi>,
  *   out[5] ms in the remaining recursion kernels, out[6] host ms (region bookkeeping + transfers),
- *   out[7] 1 if the timed H|psi> kernel also forms the A_n partial (VALU / fused variants), else 0.
+ *   out[7] 1 if the timed H|psi> kernel also forms the A_n partial (VALU / fused variants), else 0,
+ *   out[8] matrix flops EXECUTED by the timed k_spmm5 launches (padding of the MFMA tiles included, structural zeros of spin-diagonal
+ *          blocks not: they are skipped), counted for the operator class of the last atom type; 0 for the other kernels.
  * After rsrec_block_green: out[0] = kernel + transfers, out[1] = the Green kernel alone. */
 int rsrec_get_timing(rsrec_t *h, double *out, int n);
 

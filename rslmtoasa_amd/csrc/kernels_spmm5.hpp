@@ -72,6 +72,7 @@ struct Spmm5Operator {
     struct Entry { const double* blk; int col; int flip; };        // blk == nullptr: null entry (zero fragments, reads the zero block)
     struct Head { std::vector<double> blk; int flip = 0; bool valid = false; };
     std::vector<Head> head_main;   // [set][tau]: first regular entry of the schedule (its first two orbitals share triple 1 with the extra entries)
+    std::vector<int> ksteps;       // [set][tau]: MFMA k-steps a wave runs per group (X, Y steps: 2, Z steps: 1)
 
     void release() {
         if (d_frag) (void)hipFree(d_frag);
@@ -134,6 +135,7 @@ struct Spmm5Operator {
         std::vector<std::vector<Entry>> sched((size_t)nset * ntau);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
         head_main.assign((size_t)nset * ntau, Head());
+        ksteps.assign((size_t)nset * ntau, 0);
         int maxent = 0;
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
@@ -155,6 +157,7 @@ struct Spmm5Operator {
                     if (Spmm4Operator::pattern_of(B[s]) == 0) E.push_back({B[s], s, 1});
                 }
                 M[0] = steps_of((int)E.size());
+                ksteps[(size_t)set * ntau + tau] = 5 * (M[0] / 3) + 2 * (M[0] % 3);
                 for (int j = 0; j < S5_MAXENT + S5_ENTPAD; ++j)
                     M[2 + j] = j < (int)E.size() ? ((E[j].blk ? E[j].col : null_col) | (E[j].flip << 8)) : null_col;
                 maxent = std::max(maxent, (int)E.size());
@@ -224,6 +227,9 @@ struct Spmm5Operator {
             }
         return build_custom(nslots_lat, nt, nset, blk);
     }
+    // matrix flops one group of 8 atoms costs in set `set` (both spin waves; class of the last atom type -- the bulk atoms): per k-step
+    // nine tiles of one 16x16x4 and one 4x4x4 (4 blocks) MFMA
+    double flops_per_group(int set) const { return ksteps.empty() ? 0.0 : 2.0 * ksteps[(size_t)set * ntau + ntau - 1] * 9.0 * (2.0 * 16 * 16 * 4 + 2.0 * 4 * 4 * 4 * 4); }
     const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * 2 * ntr * S5_TRIPLE; }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
 };

@@ -97,7 +97,7 @@ struct rsrec_handle {
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
-    double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0;
+    double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
     int hop_fuses_a = 1;      // 1: the timed H|psi> kernel also forms pmn and the A_n partial (VALU path); 0: pure SpMM (MFMA path)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -109,12 +109,14 @@ struct rsrec_handle {
         double atom_steps, block_mults;
         DevBuf order, cum;
         std::vector<int> level_max;     // per level: largest active-atom count over the chains of this entry
+        std::vector<double> level_groups;   // per level: groups of 8 atoms (padding included) summed over the chains
     };
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
     const int* cur_order = nullptr;
     const int* cur_cum = nullptr;     // [nrows][nlev] counts, followed by [nrows][nlev] list offsets
     const std::vector<int>* cur_level_max = nullptr;
+    const std::vector<double>* cur_level_groups = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
     // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root)
@@ -356,8 +358,8 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
 
 extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
     if (!h || !out) return RSREC_ERR_ARG;
-    const double v[8] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    const double v[9] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop};
+    for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
     return RSREC_OK;
 }
 
@@ -590,7 +592,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     for (auto* e : h->region_cache)
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
-            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max;
+            h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
@@ -704,15 +706,19 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     XFER(xfer_h2d(h, e->cum.p, cum.data(), cum.size() * 4));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
     e->level_max.assign(nlev, 0);
+    e->level_groups.assign(nlev, 0.0);
     for (int c = 0; c < nb; ++c)
-        for (int l = 0; l < nlev; ++l) e->level_max[l] = std::max(e->level_max[l], cum[(size_t)c * nlev + l]);
-    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max;
+        for (int l = 0; l < nlev; ++l) {
+            e->level_max[l] = std::max(e->level_max[l], cum[(size_t)c * nlev + l]);
+            e->level_groups[l] += cum[(size_t)c * nlev + l] / GROUP;
+        }
+    h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
     return RSREC_OK;
 }
 
 void reset_timing(rsrec_t* h) {
     h->t_total_ms = h->t_hop_ms = h->t_rest_ms = h->t_host_ms = 0;
-    h->n_hop_launch = h->n_atom_steps = h->n_block_mult = 0;
+    h->n_hop_launch = h->n_atom_steps = h->n_block_mult = h->n_hop_mfma_flop = 0;
     h->ev_used = 0;
 }
 
@@ -786,6 +792,8 @@ template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
     k_spmm5<TWO><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau);
+    if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)
+        h->n_hop_mfma_flop += (*h->cur_level_groups)[SD.level] * op.flops_per_group(set);
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)

@@ -18,7 +18,7 @@ run_bench() { # name args...
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r=d["roofline"]
-print("   %s: %.1f TFLOP/s  %.1f ms/step  %.1f sites/s  frac_kernel %.3f frac_step %.3f hop %.3f ms  cpu %s" % (d["config"]["workload_key"], d["value"]*1e-3, d["ms_per_step"], d["sites_per_s"], r["frac_kernel"], r["frac_step"], r["avg_launch_ms"], d.get("cpu_baseline",{}).get("value")))
+print("   %s: %.1f TFLOP/s  %.1f ms/step  %.1f sites/s  frac_kernel %.3f (executed %.3f) frac_step %.3f hop %.3f ms  cpu %s" % (d["config"]["workload_key"], d["value"]*1e-3, d["ms_per_step"], d["sites_per_s"], r["frac_kernel"], r.get("executed",{}).get("frac",0), r["frac_step"], r["avg_launch_ms"], d.get("cpu_baseline",{}).get("value")))
 PY
 }
 if has default; then run_bench default --steps 5 --warmup 1; BENCH_EXTRA="" tools/profile_bench.sh ${TAG}_c2 block_c22_s64_l50 > $O/prof_c2.log 2>&1 || { tail -20 $O/prof_c2.log; exit 1; }; fi
