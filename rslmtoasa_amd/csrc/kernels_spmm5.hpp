@@ -322,6 +322,7 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
     load_idx(code_cur & 255);
     int ebase = 0, tbase = 0;
     bool first = true;
+    unsigned vlane_main = lane_main, vlane_z = lane_z, vlane16 = lane16, vlane8 = lane8;
     // entry j (its indices are in raw, its code in code_cur) becomes addressable; the indices of entry j + 1 are requested
     auto open_entry = [&](int j, S5Ent& E) {
         const unsigned so = 2592u * (unsigned)((code_cur >> 8) ? 1 - sig : sig);
@@ -349,10 +350,13 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
         s5_gp fbg = (s5_gp)fb;
         asm("" : "+s"(fbg));
         constexpr unsigned rowA = 288u * I::mA0, rowB = 0u - 288u * I::sp;
-        unsigned lm = I::K < 2 ? lane_main : lane_z, lf = I::K < 2 ? lane16 : lane8;
+        // the lane parts as values (re)defined in this step's block: instruction selection then folds base (SGPR pair) + lane (32-bit VGPR)
+        // + immediate into the load (a zero-extension hoisted out of the loop made every address a 64-bit vector add).  They are
+        // redefined IN PLACE (one register each for the whole loop): a per-step copy landed in a register of the operand set about to be
+        // loaded, and the write-after-write check against that set's older loads became a vmcnt(0) at the top of every step.
+        unsigned& lm = I::K < 2 ? vlane_main : vlane_z;
+        unsigned& lf = I::K < 2 ? vlane16 : vlane8;
         const unsigned lr = I::K < 2 ? lane_rem : lane_rem_z;
-        // the lane parts as values defined in this step's block: instruction selection then folds base (SGPR pair) + lane (32-bit VGPR) +
-        // immediate into the load (a zero-extension hoisted out of the loop made every address a 64-bit vector add)
         asm volatile("" : "+v"(lm));
         asm volatile("" : "+v"(lf));
         using V = std::remove_reference_t<decltype(o.b[0])>;

@@ -9,8 +9,10 @@ from rslmtoasa_amd.recursion import Recursion
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    p = supercell_problem((22, 22, 22))
-    rec = Recursion(*objects_from(p, np.arange(1, n + 1, dtype=np.int32) * 97, 50))
+    c = int(os.environ.get("CELLS", "22"))
+    lld = int(os.environ.get("LLD", "50"))
+    p = supercell_problem((c, c, c))
+    rec = Recursion(*objects_from(p, np.arange(1, n + 1, dtype=np.int32) * 97 % (c ** 3) + 1, lld))
     for kv in sys.argv[2:]:
         k, v = kv.split("=")
         rec.set_option(k, int(v))
