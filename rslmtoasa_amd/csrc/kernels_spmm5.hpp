@@ -61,7 +61,7 @@ constexpr int S5_TRIPLE_BYTES = S5_TRIPLE * 8;
 constexpr int S5_HEAD_TRIPLES = 2;                                 // the triples that hold the two extra entries (orbitals 0..17)
 constexpr int S5_HEAD_DOUBLES = 2 * S5_HEAD_TRIPLES * S5_TRIPLE;   // per-chain head of a stream: [sigma_out][2 triples][640]
 constexpr int S5_MAXENT = 2 * S4_MAXSLOTS + 2;                     // diagonal and spin-flip part of every slot + the two extra entries
-constexpr int S5_ENTPAD = 4;                                       // null entries behind the list (operands are requested two steps ahead)
+constexpr int S5_ENTPAD = 8;                                       // null entries behind the list (operands are requested two steps ahead)
 
 struct Spmm5Operator {
     double* d_frag = nullptr;    // [set][tau][sigma_out][ntr][640]
