@@ -1,0 +1,100 @@
+"""H|psi> of the matrix-core SpMM (k_spmm5, through rsrec_apply_operator) against a plain numpy restatement of the reference's
+ham_vec_matmul / ham_hoh_vec_matmul (recursion.f90:913 / :785) on RANDOM ragged lattices: up to the kernel's maximum of 31 neighbour
+slots, atoms with missing neighbours (0 entries), several atom types, per-atom (impurity) blocks, spin-diagonal and spin-mixing
+blocks, with and without hoh.  The schedule of the kernel (a stream of 9-orbital entries cut into steps of 4/4/2 orbitals with a
+27-step period) sees every tail length and entry count here; the fixtures of the other tests only a few.
+"""
+import numpy as np
+import pytest
+
+from helpers import objects_from
+from rslmtoasa_amd.recursion import Recursion
+
+pytestmark = pytest.mark.gpu
+
+
+def random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear):
+    nn = np.zeros((kk, nslots + 1), np.int32, order="F")
+    for k in range(kk):
+        nr = nslots if k % 7 else int(rng.integers(1, nslots + 1))     # most atoms full, some with fewer slots
+        nn[k, 0] = nr
+        for nb in range(2, nr + 1):
+            nn[k, nb - 1] = 0 if rng.random() < 0.1 else int(rng.integers(1, kk + 1))   # 0 = absent neighbour
+    nn[kk - 1, 0] = nslots                                               # at least one atom uses every slot
+    iz = rng.integers(1, ntype + 1, kk).astype(np.int32)
+
+    def blocks(n, last):
+        a = (rng.standard_normal((18, 18, n, last)) + 1j * rng.standard_normal((18, 18, n, last))) * 0.2
+        if collinear:                                                    # hopping blocks of a collinear magnet: no spin-flip part
+            a[:9, 9:] = 0
+            a[9:, :9] = 0
+        return np.asfortranarray(a)
+
+    p = dict(nn=nn, iz=iz, nmax=nmax, hoh=int(hoh), nsp=2, ee=blocks(nslots, ntype),
+             lsham=np.asfortranarray((rng.standard_normal((18, 18, ntype)) + 1j * rng.standard_normal((18, 18, ntype))) * 0.1))
+    if nmax:
+        p["hall"] = blocks(nslots, nmax)
+    if hoh:
+        p["eeo"] = blocks(nslots, ntype)
+        p["enim"] = np.asfortranarray((rng.standard_normal((18, 18, ntype)) + 1j * rng.standard_normal((18, 18, ntype))) * 0.1)
+        if nmax:
+            p["hallo"] = blocks(nslots, nmax)
+    return p
+
+
+def apply_blocks(p, x, use_o):
+    """sum over the slots of block(slot, class of k) @ x[neighbour]: the loops of recursion.f90:935-975 with every atom active."""
+    kk = x.shape[2]
+    out = np.zeros_like(x)
+    for k in range(kk):
+        if k < p["nmax"]:
+            H = (p["hallo"] if use_o else p["hall"])[:, :, :, k]
+        else:
+            H = (p["eeo"] if use_o else p["ee"])[:, :, :, p["iz"][k] - 1]
+        acc = H[:, :, 0] @ x[:, :, k]
+        for nb in range(2, p["nn"][k, 0] + 1):
+            n = p["nn"][k, nb - 1]
+            if n:
+                acc = acc + H[:, :, nb - 1] @ x[:, :, n - 1]
+        out[:, :, k] = acc
+    return out
+
+
+def ham_vec_numpy(p, x, a, b):
+    ls = np.stack([p["lsham"][:, :, t - 1] for t in p["iz"]], axis=2)
+    soc = np.einsum("ijk,jlk->ilk", ls, x)
+    if not p["hoh"]:
+        out = apply_blocks(p, x, False) + soc
+    else:
+        en = np.einsum("ijk,jlk->ilk", np.stack([p["enim"][:, :, t - 1] for t in p["iz"]], axis=2), x)
+        h = apply_blocks(p, x, False)
+        out = h - apply_blocks(p, h, True) + en + soc                    # :905
+    return (out - b * x) / a
+
+
+CASES = [  # kk, nslots, ntype, nmax, hoh, collinear
+    (150, 31, 3, 4, False, False),
+    (150, 31, 3, 4, True, False),
+    (233, 31, 2, 0, False, True),
+    (233, 30, 2, 3, True, True),
+    (97, 1, 1, 0, False, False),
+    (97, 2, 2, 1, True, True),
+    (180, 15, 1, 0, False, True),
+    (180, 19, 4, 7, False, True),
+    (180, 13, 4, 7, True, False),
+    (64, 9, 2, 2, True, True),
+]
+
+
+@pytest.mark.parametrize("kk,nslots,ntype,nmax,hoh,collinear", CASES)
+def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, collinear):
+    rng = np.random.default_rng(1000 * kk + 10 * nslots + ntype + 2 * int(hoh) + int(collinear))
+    p = random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear)
+    rec = Recursion(*objects_from(p, np.array([1], np.int32), 4), device=0)
+    x = np.asfortranarray(rng.standard_normal((18, 18, kk)) + 1j * rng.standard_normal((18, 18, kk)))
+    a, b = 1.7, -0.3
+    want = ham_vec_numpy(p, x, a, b)
+    got = rec.ham_vec_matmul(x, a, b)
+    rec.close()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-13 * scale
