@@ -98,3 +98,40 @@ def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, 
     rec.close()
     scale = np.abs(want).max()
     assert np.abs(got - want).max() <= 2e-13 * scale
+
+
+RECUR_CASES = [  # kk, nslots, ntype, nmax, hoh, collinear
+    (120, 31, 3, 4, False, False),
+    (120, 22, 2, 3, True, True),
+    (90, 7, 2, 0, True, False),
+    (140, 14, 1, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2, "ci"])
+@pytest.mark.parametrize("kk,nslots,ntype,nmax,hoh,collinear", RECUR_CASES)
+def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, collinear, variant, oracle_lib):
+    """Block Lanczos and Chebyshev moments on the same random lattices (region growth through missing neighbours and impurity atoms)
+    against the CPU oracle, for the VALU set, the matrix-core set and the matrix-core set with the large-launch SpMM forced."""
+    from helpers import RTOL, rel_err
+    rng = np.random.default_rng(77 + kk + nslots)
+    p = random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear)
+    irec = np.array([1, kk // 2, kk], np.int32)          # an impurity atom (if any), a bulk atom, the last atom
+    lld = 6
+    rec = Recursion(*objects_from(p, irec, lld, emin=-60.0, emax=60.0), device=0)
+    if variant == "ci":
+        rec.set_option("kernels", 2)
+        rec.set_option("spmm5", 2)
+    else:
+        rec.set_option("kernels", variant)
+    o = oracle_lib.Oracle(p)
+    rec.recur_b()
+    a_o, b_o = o.block_lanczos(irec, lld)
+    assert rel_err(rec.a_b, a_o) < RTOL and rel_err(rec.b2_b, b_o) < RTOL
+    rec.chebyshev_recur()
+    from rslmtoasa_amd.recursion import chebyshev_scaling
+    a, b = chebyshev_scaling(-60.0, 60.0)                        # recursion.f90:3078-3079
+    mu_o, div = o.chebyshev(irec, lld, a, b)
+    assert div == 0
+    assert rel_err(rec.mu_n, mu_o) < RTOL
+    rec.close()
