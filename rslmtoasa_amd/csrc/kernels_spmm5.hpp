@@ -67,7 +67,7 @@ struct Spmm5Operator {
     double* d_frag = nullptr;    // [set][tau][sigma_out][ntr][640]
     int* d_meta = nullptr;       // [set][tau][META]: number of steps, number of extra entries (0 / 2), entry codes column | flip << 8
     size_t frag_bytes = 0, meta_bytes = 0;
-    int ntau = 0, nslots = 0, have_o = 0, ntr = 0;
+    int ntau = 0, nslots = 0, have_o = 0, ntr = 0, spin_mixing = 0;   // spin_mixing: some regular (hopping) block has a spin-flip part
     static constexpr int META = 2 + S5_MAXENT + S5_ENTPAD;
     struct Entry { const double* blk; int col; int flip; };        // blk == nullptr: null entry (zero fragments, reads the zero block)
     struct Head { std::vector<double> blk; int flip = 0; bool valid = false; };
@@ -130,7 +130,7 @@ struct Spmm5Operator {
     // of every block, plus the spin-flip part of the blocks that have one.
     const char* build_custom(int nslots_lat, int ntau_, int nset, const std::vector<const double*>& blk) {
         if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
-        ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0;
+        ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0; spin_mixing = 0;
         const int nfs = nslots + 1, null_col = nslots + 1;
         std::vector<std::vector<Entry>> sched((size_t)nset * ntau);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
@@ -154,7 +154,7 @@ struct Spmm5Operator {
                         H.blk.assign(B[s], B[s] + 2 * BLK); H.flip = 0; H.valid = true;
                     }
                     E.push_back({B[s], s, 0});
-                    if (Spmm4Operator::pattern_of(B[s]) == 0) E.push_back({B[s], s, 1});
+                    if (Spmm4Operator::pattern_of(B[s]) == 0) { E.push_back({B[s], s, 1}); if (s > 0) spin_mixing = 1; }
                 }
                 M[0] = steps_of((int)E.size());
                 ksteps[(size_t)set * ntau + tau] = 5 * (M[0] / 3) + 2 * (M[0] % 3);
@@ -227,6 +227,13 @@ struct Spmm5Operator {
             }
         return build_custom(nslots_lat, nt, nset, blk);
     }
+    // the one operator class of set `set` that has a schedule, or -1 if several have (then groups of different classes meet in a launch)
+    int single_class(int set) const {
+        int one = -1;
+        for (int tau = 0; tau < ntau; ++tau)
+            if (ksteps[(size_t)set * ntau + tau] > 0) { if (one >= 0) return -1; one = tau; }
+        return one;
+    }
     // matrix flops one group of 8 atoms costs in set `set` (both spin waves; class of the last atom type -- the bulk atoms): per k-step
     // nine tiles of one 16x16x4 and one 4x4x4 (4 blocks) MFMA
     double flops_per_group(int set) const { return ksteps.empty() ? 0.0 : 2.0 * ksteps[(size_t)set * ntau + ntau - 1] * 9.0 * (2.0 * 16 * 16 * 4 + 2.0 * 4 * 4 * 4 * 4); }
@@ -266,6 +273,7 @@ __device__ __forceinline__ void s5_interleave() {
     __builtin_amdgcn_sched_group_barrier(0x8, NM - PER * NL, 0);
 }
 
+template <int NL = 11>
 __device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Pair& o) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -274,20 +282,22 @@ __device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Pair& o) {
             acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0][e], o.b[t][e], acc.m[t], 0, 0, 0);
             acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1][e], o.b[t][e], acc.r[t], 0, 0, 0);
         }
-    s5_interleave<11, 36>();
+    s5_interleave<NL, 36>();
 }
+template <int NL = 11>
 __device__ __forceinline__ void s5_mfma(S5Acc& acc, const S5Single& o) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0], o.b[t], acc.m[t], 0, 0, 0);
         acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1], o.b[t], acc.r[t], 0, 0, 0);
     }
-    s5_interleave<11, 18>();
+    s5_interleave<NL, 18>();
 }
 
 template <int N> using S5C = std::integral_constant<int, N>;
 #define S5_GLOBAL __attribute__((address_space(1)))
 #define S5_CONST __attribute__((address_space(4)))
+#define S5_LDS __attribute__((address_space(3)))
 typedef const S5_GLOBAL char* s5_gp;      // explicit global address space: the loads stay global_load behind the scalar-base barriers below
 
 // The whole stream of a group for one wave (output spin `sig`).  Operands are requested TWO steps ahead into three register sets
@@ -298,8 +308,8 @@ typedef const S5_GLOBAL char* s5_gp;      // explicit global address space: the 
 // TWO: the first two entries (18 orbitals = steps 0..4 of the first period) are the extra on-site slot; they read the second input
 // vector in2b (hoh second pass, recursion.f90:1543: the (e_nu + l.s) term acts on psi itself; local-axis runs: the per-chain on-site
 // term), and if fr_head is given the first two triples of fragments come from that per-chain table.
-template <bool TWO>
-__device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict__ meta, const char* __restrict__ fr, const char* __restrict__ fr_head,
+template <bool TWO, bool LDSA>
+__device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict__ meta, const char* __restrict__ fr /*LDSA: the staged stream in LDS*/, const char* __restrict__ fr_head,
                                               const char* __restrict__ inb, const char* __restrict__ in2b,
                                               const int* __restrict__ nbr5 /*(kk+1) x ncol: absent -> zero block, column nslots = self, nslots + 1 = zero block*/,
                                               const int (&atom)[GROUP] /*padding -> zero block*/, int rem_sel /*per lane: tile (atom of the group) of its remainder column*/,
@@ -344,11 +354,14 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
         if constexpr (I::opens) open_entry(ebase + 10 * wrap + I::eOpen, (I::eOpen & 1) ? E1 : E0);
         const bool head = wrap == 0 && first && extras;
         const char* __restrict__ base = (TWO && S < 5 && head) ? in2b : inb;
-        const char* fb = ((TWO && I::T < S5_HEAD_TRIPLES && head && fr_head) ? fr_head + I::T * S5_TRIPLE_BYTES
-                                                                                         : fr + (size_t)(tbase + 9 * wrap + I::T) * S5_TRIPLE_BYTES)
-                                      + (I::K == 0 ? 0 : I::K == 1 ? 2048 : 4096);
-        s5_gp fbg = (s5_gp)fb;
-        asm("" : "+s"(fbg));
+        s5_gp fbg = nullptr;
+        if constexpr (!LDSA) {
+            const char* fb = ((TWO && I::T < S5_HEAD_TRIPLES && head && fr_head) ? fr_head + I::T * S5_TRIPLE_BYTES
+                                                                                 : fr + (size_t)(tbase + 9 * wrap + I::T) * S5_TRIPLE_BYTES)
+                             + (I::K == 0 ? 0 : I::K == 1 ? 2048 : 4096);
+            fbg = (s5_gp)fb;
+            asm("" : "+s"(fbg));
+        }
         constexpr unsigned rowA = 288u * I::mA0, rowB = 0u - 288u * I::sp;
         // the lane parts as values (re)defined in this step's block: instruction selection then folds base (SGPR pair) + lane (32-bit VGPR)
         // + immediate into the load (a zero-extension hoisted out of the loop made every address a 64-bit vector add).  They are
@@ -378,7 +391,12 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
             const unsigned off = (inB ? EB.rem + rowB : EA.rem + rowA) + lr;
             o.b[8] = *(const S5_GLOBAL V*)((s5_gp)base + off);
         }
-        if constexpr (I::K < 2) {
+        if constexpr (LDSA) {
+            // operator fragments from the workgroup's LDS copy of the stream: LDS reads do not pass the texture addresser
+            const S5_LDS char* fl = (const S5_LDS char*)fr + (unsigned)(tbase + 9 * wrap + I::T) * S5_TRIPLE_BYTES + (I::K == 0 ? 0 : I::K == 1 ? 2048 : 4096);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) o.a[q] = *(const S5_LDS V*)(fl + lf + q * (I::K < 2 ? 1024 : 512));
+        } else if constexpr (I::K < 2) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) o.a[q] = *(const S5_GLOBAL V*)(fbg + lf + q * 1024);
         } else {
@@ -393,7 +411,7 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
 #define S5_STEP(S, NEXT, CUR)                 \
     if (left > (S)) {                         \
         issue(S5C<(S) + 2>{}, NEXT);          \
-        s5_mfma(acc, CUR);                    \
+        s5_mfma<LDSA ? 9 : 11>(acc, CUR);     \
         __builtin_amdgcn_sched_barrier(0);    \
     }
     for (;; left -= 27) {
@@ -408,19 +426,40 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
 #undef S5_STEP
 }
 
-// One wave = (group of 8 atoms, output spin).  Workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group,
-// different spin) land on the same SIMD.  Input and output vectors in the CI layout.
-template <bool TWO>
+// One wave = (group of 8 atoms, output spin).  Input and output vectors in the CI layout.
+// !LDSA: workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group, different spin) land on the same SIMD; the operator
+//        fragments are global loads (L2-resident tables).
+// LDSA:  workgroup = 8 groups of ONE output spin (the workgroup's parity); the fragment stream of that spin -- the same for every group
+//        when the operator has one class of atoms -- is copied to LDS once and read from there: the texture addresser of the CU, 83 %
+//        busy with the 11 loads per step, loses two of them (profiles/: TA_TA_BUSY).  Even XCDs then work on spin 0 and odd ones on
+//        spin 1: an XCD's L2 holds only one spin half of the neighbour blocks of a collinear operator.
+template <bool TWO, bool LDSA>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+2)*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta, int ntr,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
                                                const double* __restrict__ in2_all = nullptr,
                                                const double* __restrict__ frag_head = nullptr /*[chain][tau][S5_HEAD_DOUBLES]: per-chain head of the stream*/,
-                                               int ntau = 0) {
+                                               int ntau = 0, int lds_tau = 0 /*LDSA: the operator class whose stream is staged (all groups must be of it)*/) {
+    extern __shared__ double s5_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sig = wave / S5_WG_GROUPS, gslot = wave % S5_WG_GROUPS;
+    const int sig = LDSA ? (int)(blockIdx.x & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
+    constexpr int WGG = LDSA ? 2 * S5_WG_GROUPS : S5_WG_GROUPS;       // groups per workgroup
+    if constexpr (LDSA) {
+        const s5_d2* __restrict__ src = reinterpret_cast<const s5_d2*>(frag + ((size_t)lds_tau * 2 + sig) * ntr * S5_TRIPLE);
+        s5_d2* dst = reinterpret_cast<s5_d2*>(s5_lds);
+        // all loads of a thread in flight at once (a rolled loop paid one memory latency per iteration: the copy then cost more than
+        // the LDS reads save, because a workgroup lives for one round of groups only)
+        const int n = ntr * (S5_TRIPLE / 2);
+        constexpr int PER = (int)(160 * 1024 / 16 / (S5_WG_GROUPS * 128));     // 20: the LDS limit over the workgroup's threads
+        s5_d2 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * (S5_WG_GROUPS * 128); if (e < n) v[i] = src[e]; }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * (S5_WG_GROUPS * 128); if (e < n) dst[e] = v[i]; }
+        __syncthreads();
+    }
     const int l15 = lane & 15, l4 = lane >> 4;
     // CI layout (kernels_mfma.hpp): element (r, c) of a block = complex at doubles 36 r + 2 c; row r = 9 sigma + m.  Lane (l15, l4) of an
     // X / Y step reads element (m0 + l4, c = l15) as one 16-byte load (re, im = the step's two k-steps); of a Z step element
@@ -441,20 +480,24 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     double* __restrict__ out = out_all + vo;
     const int zero_block = D.kk;
 
-    // XCD x sweeps chunk x of the group list (workgroups are dealt round-robin over the 8 XCDs, each with its own L2)
+    // XCD x sweeps chunk x of the group list (workgroups are dealt round-robin over the 8 XCDs, each with its own L2);
+    // LDSA: XCD x sweeps quarter x >> 1 of the list for spin x & 1
     int g, gend, gstep;
     {
-        const int nbx = max(1, min((int)gridDim.x, (ngroups + S5_WG_GROUPS - 1) / S5_WG_GROUPS)), bx = blockIdx.x;
+        const int nbx = max(LDSA ? 2 : 1, min((int)gridDim.x, (LDSA ? 2 : 1) * ((ngroups + WGG - 1) / WGG))), bx = blockIdx.x;
         if (bx >= nbx) continue;                             // launch sized for the largest chain of the batch
-        if (nbx < 8) { g = bx * S5_WG_GROUPS + gslot; gend = ngroups; gstep = nbx * S5_WG_GROUPS; }
-        else {
+        if (nbx < 8) {
+            if constexpr (LDSA) { g = (bx >> 1) * WGG + gslot; gend = ngroups; gstep = ((nbx + 1 - (bx & 1)) >> 1) * WGG; }
+            else { g = bx * WGG + gslot; gend = ngroups; gstep = nbx * WGG; }
+        } else {
             const int xcd = bx & 7, j = bx >> 3;
             const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
-            const int chunk = (ngroups + 7) >> 3;
-            const int lo = xcd * chunk;
+            const int nchunk = LDSA ? 4 : 8, ichunk = LDSA ? (xcd >> 1) : xcd;
+            const int chunk = (ngroups + nchunk - 1) / nchunk;
+            const int lo = ichunk * chunk;
             gend = min(ngroups, lo + chunk);
-            g = lo + j * S5_WG_GROUPS + gslot;
-            gstep = per_xcd * S5_WG_GROUPS;
+            g = lo + j * WGG + gslot;
+            gstep = per_xcd * WGG;
         }
     }
     for (; g < gend; g += gstep) {
@@ -467,14 +510,14 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         int my_rem_atom = grp[l15 >> 1];
         my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
-        const char* __restrict__ fr = reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);
+        const char* __restrict__ fr = LDSA ? reinterpret_cast<const char*>(s5_lds) : reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);
         const char* __restrict__ fh = (TWO && frag_head) ? reinterpret_cast<const char*>(frag_head + ((size_t)chain * ntau + tau) * S5_HEAD_DOUBLES + (size_t)sig * S5_HEAD_TRIPLES * S5_TRIPLE) : nullptr;
 
         S5Acc acc;
 #pragma unroll
         for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
 
-        s5_run_stream<TWO>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
+        s5_run_stream<TWO, LDSA>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI

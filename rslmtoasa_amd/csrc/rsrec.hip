@@ -94,7 +94,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
@@ -351,6 +351,8 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "spmm5")) h->opt_spmm5 = value;
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
+    else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
+    else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -787,11 +789,29 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
     return out;
 }
 
-// k_spmm5 launch (large launches; CI vectors)
+// k_spmm5 launch (large launches; CI vectors).  The variant with the operator fragments in LDS serves operators with ONE class of
+// atoms (a bulk crystal of one type: every group runs the same stream) whose stream of one spin fits the CU's LDS; per-chain stream
+// heads (local-axis runs) keep the global-load variant.
+constexpr size_t S5_LDS_LIMIT = 160 * 1024;
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
-    k_spmm5<TWO><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau);
+    const size_t lds_bytes = (size_t)op.ntr * S5_TRIPLE * sizeof(double);
+    const int one = op.single_class(set);
+    // s5_lds: 0 never, 1 (default) where it was measured to pay -- hoh operators (-3.7 % per launch; within +-1 % on the plain, 46^3 and
+    // Chebyshev workloads; a spin-mixing stencil loses 25 %: both spin halves of a block are then fetched into two XCDs' L2), 2 whenever possible
+    const bool want = h->opt_s5_lds >= 2 || (h->opt_s5_lds == 1 && op.have_o && !op.spin_mixing);
+    if (want && one >= 0 && !extra && lds_bytes <= S5_LDS_LIMIT) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS_LIMIT);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS_LIMIT);
+            attr = true;
+        }
+        dim3 g2(std::max(2u, grid.x), grid.y);
+        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one);
+    } else
+        k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0);
     if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)
         h->n_hop_mfma_flop += (*h->cur_level_groups)[SD.level] * op.flops_per_group(set);
 }

@@ -36,6 +36,12 @@ def close(got, exp, abs_tol, rel_tol):
     return d <= abs_tol or d <= rel_tol * abs(exp)
 
 
+def fortran_float(tok):
+    """A Fortran es16.6 field: exponents of three digits are written without the 'E' (-1.880039+133)."""
+    m = re.fullmatch(r"([-+]?[0-9.]+)([-+][0-9]{3})", tok)
+    return float(m.group(1) + "e" + m.group(2)) if m else float(tok.replace("D", "E").replace("d", "e"))
+
+
 @pytest.mark.parametrize("name", sorted(MANIFEST))
 def test_scf_workflow_with_gpu_recursion(name, tmp_path):
     case = MANIFEST[name]
@@ -77,7 +83,7 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
         for row, cols in rows.items():
             vals = lines[int(row) - 1].split()
             for col, e in cols.items():
-                got = float(vals[int(col) - 1])
+                got = fortran_float(vals[int(col) - 1])
                 if not close(got, e, at, rt):
                     bad.append((fn, row, col, got, e))
     assert not bad, bad

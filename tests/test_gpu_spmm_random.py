@@ -80,6 +80,8 @@ CASES = [  # kk, nslots, ntype, nmax, hoh, collinear
     (97, 1, 1, 0, False, False),
     (97, 2, 2, 1, True, True),
     (180, 15, 1, 0, False, True),
+    (180, 15, 1, 0, True, True),
+    (150, 31, 1, 0, True, False),
     (180, 19, 4, 7, False, True),
     (180, 13, 4, 7, True, False),
     (64, 9, 2, 2, True, True),
@@ -91,6 +93,7 @@ def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, 
     rng = np.random.default_rng(1000 * kk + 10 * nslots + ntype + 2 * int(hoh) + int(collinear))
     p = random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear)
     rec = Recursion(*objects_from(p, np.array([1], np.int32), 4), device=0)
+    rec.set_option("s5_lds", 2)      # single-class operators: the variant with the operator stream in LDS
     x = np.asfortranarray(rng.standard_normal((18, 18, kk)) + 1j * rng.standard_normal((18, 18, kk)))
     a, b = 1.7, -0.3
     want = ham_vec_numpy(p, x, a, b)
