@@ -440,11 +440,13 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
                                                const double* __restrict__ in2_all = nullptr,
                                                const double* __restrict__ frag_head = nullptr /*[chain][tau][S5_HEAD_DOUBLES]: per-chain head of the stream*/,
-                                               int ntau = 0, int lds_tau = 0 /*LDSA: the operator class whose stream is staged (all groups must be of it)*/) {
+                                               int ntau = 0, int lds_tau = 0 /*LDSA: the operator class whose stream is staged (all groups must be of it)*/,
+                                               int* __restrict__ queue = nullptr /*LDSA: [chain][16] group counters, zero at launch: persistent workgroups, one group per pull*/,
+                                               int spin_by_xcd = 1 /*LDSA: 1: even XCDs spin 0, odd spin 1 (collinear operators); 0: both spins on every XCD*/) {
     extern __shared__ double s5_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sig = LDSA ? (int)(blockIdx.x & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
+    const int sig = LDSA ? (int)((spin_by_xcd ? blockIdx.x : (blockIdx.x >> 3)) & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
     constexpr int WGG = LDSA ? 2 * S5_WG_GROUPS : S5_WG_GROUPS;       // groups per workgroup
     if constexpr (LDSA) {
         const s5_d2* __restrict__ src = reinterpret_cast<const s5_d2*>(frag + ((size_t)lds_tau * 2 + sig) * ntr * S5_TRIPLE);
@@ -481,26 +483,62 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int zero_block = D.kk;
 
     // XCD x sweeps chunk x of the group list (workgroups are dealt round-robin over the 8 XCDs, each with its own L2);
-    // LDSA: XCD x sweeps quarter x >> 1 of the list for spin x & 1
-    int g, gend, gstep;
+    // LDSA, spin_by_xcd: XCD x sweeps quarter x >> 1 of the list for spin x & 1 -- an XCD's L2 then holds one spin half of the neighbour
+    // blocks of a collinear operator; LDSA, !spin_by_xcd (spin-mixing operators read both halves): the workgroups of an XCD alternate
+    // between the spins and share the XCD's eighth of the list
+    int g, gend, gstep, glo = 0;
+    bool dynamic = false;
     {
-        const int nbx = max(LDSA ? 2 : 1, min((int)gridDim.x, (LDSA ? 2 : 1) * ((ngroups + WGG - 1) / WGG))), bx = blockIdx.x;
-        if (bx >= nbx) continue;                             // launch sized for the largest chain of the batch
-        if (nbx < 8) {
-            if constexpr (LDSA) { g = (bx >> 1) * WGG + gslot; gend = ngroups; gstep = ((nbx + 1 - (bx & 1)) >> 1) * WGG; }
-            else { g = bx * WGG + gslot; gend = ngroups; gstep = nbx * WGG; }
+        const int bx = blockIdx.x;
+        const int need = (ngroups + WGG - 1) / WGG;               // workgroups one round of the chain takes (per spin for LDSA)
+        if constexpr (!LDSA) {
+            const int nbx = max(1, min((int)gridDim.x, need));
+            if (bx >= nbx) continue;                             // launch sized for the largest chain of the batch
+            if (nbx < 8) { g = bx * WGG + gslot; gend = ngroups; gstep = nbx * WGG; }
+            else {
+                const int xcd = bx & 7, j = bx >> 3;
+                const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
+                const int chunk = (ngroups + 7) >> 3;
+                const int lo = xcd * chunk;
+                gend = min(ngroups, lo + chunk);
+                g = lo + j * WGG + gslot;
+                gstep = per_xcd * WGG;
+            }
         } else {
+            // whole rows of 8 (spin_by_xcd) or 16 (both spins per XCD) workgroups; a chain too short for one row per XCD chunk is dealt
+            // over the first row as one list
+            const int row = spin_by_xcd ? 8 : 16;
+            const int nbx = max(row, min((int)gridDim.x / row * row, (2 * need + row - 1) / row * row));
+            if (bx >= nbx) continue;
             const int xcd = bx & 7, j = bx >> 3;
-            const int per_xcd = (nbx >> 3) + ((xcd < (nbx & 7)) ? 1 : 0);
-            const int nchunk = LDSA ? 4 : 8, ichunk = LDSA ? (xcd >> 1) : xcd;
-            const int chunk = (ngroups + nchunk - 1) / nchunk;
-            const int lo = ichunk * chunk;
-            gend = min(ngroups, lo + chunk);
-            g = lo + j * WGG + gslot;
-            gstep = per_xcd * WGG;
+            if (2 * need <= row) {                               // short chain: the first row, 4 (8) workgroups per spin
+                const int per_spin = row / 2, idx = spin_by_xcd ? (xcd >> 1) : xcd;
+                if (j >= row / 8) continue;
+                g = idx * WGG + gslot; gend = ngroups; gstep = per_spin * WGG;
+            } else {
+                const int rows = nbx / row;                      // workgroups of this spin on this XCD
+                const int nchunk = spin_by_xcd ? 4 : 8, ichunk = spin_by_xcd ? (xcd >> 1) : xcd;
+                const int chunk = (ngroups + nchunk - 1) / nchunk;
+                const int lo = ichunk * chunk;
+                gend = min(ngroups, lo + chunk);
+                g = lo + (spin_by_xcd ? j : (j >> 1)) * WGG + gslot;
+                gstep = rows * WGG;
+                glo = lo;
+                dynamic = queue != nullptr;
+            }
         }
     }
-    for (; g < gend; g += gstep) {
+    // queue mode (LDSA, grid.x a multiple of 8, few long-lived workgroups): the waves of XCD x take the groups of its chunk one at a
+    // time from the chain's counter x -- the copy of the operator stream into LDS is paid once per workgroup, the balancing stays
+    // dynamic at the granularity of one group; every wave leaves when the counters of all its chains have run past their chunks
+    int* __restrict__ ctr = dynamic ? queue + (size_t)chain * 16 + 2 * (blockIdx.x & 7) + (spin_by_xcd ? 0 : sig) : nullptr;
+    for (;; g += gstep) {
+        if (dynamic) {
+            int gi = 0;
+            if (lane == 0) gi = atomicAdd(ctr, 1);
+            g = glo + __builtin_amdgcn_readfirstlane(gi);
+        }
+        if (g >= gend) break;
         const int* __restrict__ grp = order + (size_t)g * GROUP;
         int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the step loop
 #pragma unroll

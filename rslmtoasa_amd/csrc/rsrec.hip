@@ -81,6 +81,7 @@ struct rsrec_handle {
     Spmm4Operator s4_op;
     int s4_built_split = 0;
     Spmm5Operator s5_op;
+    DevBuf d_s5queue;            // group counters of the persistent k_spmm5 form
     int s5_built = 0;
     std::vector<double> host_ee, host_lsham, host_eeo, host_enim, host_hall, host_hallo;   // operator arrays as last set (Kubo operator tables; local-axis runs)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
@@ -94,7 +95,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
@@ -317,7 +318,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+    DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_s5queue, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_partial2, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
     for (auto b : all) b->release();
@@ -352,7 +353,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "chain_fold")) h->opt_chain_fold = value;
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
+    else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
     else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
+    else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -798,9 +801,8 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
     const size_t lds_bytes = (size_t)op.ntr * S5_TRIPLE * sizeof(double);
     const int one = op.single_class(set);
-    // s5_lds: 0 never, 1 (default) where it was measured to pay -- hoh operators (-3.7 % per launch; within +-1 % on the plain, 46^3 and
-    // Chebyshev workloads; a spin-mixing stencil loses 25 %: both spin halves of a block are then fetched into two XCDs' L2), 2 whenever possible
-    const bool want = h->opt_s5_lds >= 2 || (h->opt_s5_lds == 1 && op.have_o && !op.spin_mixing);
+    // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
+    const bool want = h->opt_s5_lds >= 1;
     if (want && one >= 0 && !extra && lds_bytes <= S5_LDS_LIMIT) {
         static bool attr = false;
         if (!attr) {
@@ -808,8 +810,19 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS_LIMIT);
             attr = true;
         }
-        dim3 g2(std::max(2u, grid.x), grid.y);
-        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one);
+        const int spin_by_xcd = op.spin_mixing ? 0 : 1;
+        const unsigned row = spin_by_xcd ? 8 : 16;
+        dim3 g2(std::max(row, (grid.x + row - 1) / row * row), grid.y);
+        int* queue = nullptr;
+        if ((h->opt_s5_queue == 1 && grid.x >= 256) || h->opt_s5_queue >= 2) {
+            // persistent form: one workgroup per CU for the whole launch, groups from per-(chain, XCD[, spin]) counters
+            if (h->d_s5queue.reserve((size_t)SD.nchains * 16 * sizeof(int)) == hipSuccess &&
+                hipMemsetAsync(h->d_s5queue.p, 0, (size_t)SD.nchains * 16 * sizeof(int), h->stream) == hipSuccess) {
+                queue = h->d_s5queue.as<int>();
+                g2 = dim3(256, 1);
+            }
+        }
+        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd);
     } else
         k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0);
     if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)

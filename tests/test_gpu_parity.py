@@ -180,7 +180,7 @@ def test_config2_size_1e5_atoms():
 
 
 @pytest.mark.parametrize("opts", [{"spmm5": 0}, {"spmm5": 2}, {"spmm5": 2, "side_stream": 0}, {"spmm5": 0, "side_stream": 0}, {"batch": 1},
-                                  {"spmm5": 2, "chain_fold": 2}, {"spmm5": 2, "s5_cap": 8}, {"spmm5": 2, "s5_lds": 2}, {"spmm5": 2, "s5_lds": 0}])
+                                  {"spmm5": 2, "chain_fold": 2}, {"spmm5": 2, "s5_cap": 8}, {"spmm5": 2, "s5_queue": 2}, {"spmm5": 2, "s5_queue": 0}, {"spmm5": 2, "s5_lds": 0}])
 @pytest.mark.parametrize("name", ["bccFe_nsp2_block", "B2FeCo_block"])
 def test_every_block_pipeline_variant(name, opts):
     """Both SpMM kernels of the matrix-core set (small-launch k_spmm4<4> on LayoutRM vectors, k_spmm5 on CI vectors), with and without

@@ -93,7 +93,7 @@ def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, 
     rng = np.random.default_rng(1000 * kk + 10 * nslots + ntype + 2 * int(hoh) + int(collinear))
     p = random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear)
     rec = Recursion(*objects_from(p, np.array([1], np.int32), 4), device=0)
-    rec.set_option("s5_lds", 2)      # single-class operators: the variant with the operator stream in LDS
+    rec.set_option("s5_queue", 2)    # single-class operators (operator stream in LDS): persistent workgroups with a group queue
     x = np.asfortranarray(rng.standard_normal((18, 18, kk)) + 1j * rng.standard_normal((18, 18, kk)))
     a, b = 1.7, -0.3
     want = ham_vec_numpy(p, x, a, b)
