@@ -36,6 +36,10 @@
 //     The skippable steps cost exactness of the compiler's vmcnt waits at the joins (it has to assume the shortest path).  An
 //     all-pair stream (steps of 4 orbitals only, period 4 entries = 9 steps that can run without branches) needs a third two-k-step
 //     operand set: 18 registers over the 256 of a wave at two waves per SIMD.
+//   * operator stream in LDS + persistent workgroups (LDSA): the CU's texture addresser was 83 % busy with the 11 loads per step, two of
+//     which fetch fragments that are the same for every group of an operator class.  256 workgroups (one per CU, 8 waves of one spin)
+//     copy that stream to LDS once and then take groups one at a time from per-(chain, XCD) counters: -2.8 % (plain), -7.6 % (hoh),
+//     -7.5 % (spin-mixing stencil, both spins on every XCD).  With one-round workgroups the copy cost what the reads saved.
 // Tried on top of this and not adopted: a wave walking several groups with the next group's first operands requested during the
 // last entry of the current one (the group prologue -- a chain of dependent loads -- then overlaps matrix work): 1.5 % / 4 % / 7 %
 // SLOWER at 2 / 3 / 4 groups per wave; many short one-group workgroups that the hardware dispatcher balances win.
