@@ -208,7 +208,10 @@ int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
  *                vectors from 4096 groups per launch; always for hoh and local-axis runs), 2 = always k_spmm5 [1]
  *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u> [1]
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
- *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none] */
+ *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none],
+ *   "s5_lds"     k_spmm5 with the operator fragments in LDS for operators with one class of atoms: 0 = never, 1 = whenever it applies [1]
+ *   "s5_queue"   that form as 256 persistent workgroups with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
+ *                workgroups, 2 = always [1] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
 /* Timing of the last recursion call, measured with HIP events on the engine's own stream:
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,
