@@ -536,6 +536,8 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     // time from the chain's counter x -- the copy of the operator stream into LDS is paid once per workgroup, the balancing stays
     // dynamic at the granularity of one group; every wave leaves when the counters of all its chains have run past their chunks
     int* __restrict__ ctr = dynamic ? queue + (size_t)chain * 16 + 2 * (blockIdx.x & 7) + (spin_by_xcd ? 0 : sig) : nullptr;
+    // (issuing the pull for the NEXT group before the current group's work was tried: the returning atomic is the oldest entry of the
+    // in-order vmcnt queue and every operand wait of the first steps then waits for it as well -- 19 % slower)
     for (;; g += gstep) {
         if (dynamic) {
             int gi = 0;
