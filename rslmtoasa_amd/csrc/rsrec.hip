@@ -803,13 +803,20 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
     const int one = op.single_class(set);
     // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
     const bool want = h->opt_s5_lds >= 1;
-    if (want && one >= 0 && !extra && lds_bytes <= S5_LDS_LIMIT) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS_LIMIT);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S5_LDS_LIMIT);
-            attr = true;
+    // LDS a workgroup may ask for: what the device grants on request (160 KB on MI355X), asked for once per process
+    static size_t lds_limit = (size_t)-1;
+    if (lds_limit == (size_t)-1) {
+        int optin = 0;
+        lds_limit = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, h->device) == hipSuccess && optin > 64 * 1024) {
+            const int ask = (int)std::min<size_t>((size_t)optin, S5_LDS_LIMIT);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
+                lds_limit = (size_t)ask;
         }
+        (void)hipGetLastError();
+    }
+    if (want && one >= 0 && !extra && lds_bytes <= lds_limit) {
         const int spin_by_xcd = op.spin_mixing ? 0 : 1;
         const unsigned row = spin_by_xcd ? 8 : 16;
         dim3 g2(std::max(row, (grid.x + row - 1) / row * row), grid.y);
