@@ -437,6 +437,14 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
 //        when the operator has one class of atoms -- is copied to LDS once and read from there: the texture addresser of the CU, 83 %
 //        busy with the 11 loads per step, loses two of them (profiles/: TA_TA_BUSY).  Even XCDs then work on spin 0 and odd ones on
 //        spin 1: an XCD's L2 holds only one spin half of the neighbour blocks of a collinear operator.
+// Element-wise epilogue on the result block of every atom, t = H psi still in registers:
+//   kind 0: out = t.
+//   kind 1 (cheb_1st_mom, recursion.f90:2228-2236):        out = (t - b cur) / a                      (cur = psi0)
+//   kind 2 (chebyshev_recur_ll, :2548-2587):               out = ((t - b cur) / a) * 2 - old          (cur = psi1, old = psi0)
+// in the reference's operation order -- the Chebyshev step then never writes and re-reads H psi (two of the six block streams of a
+// level); its Gram matrices are formed by k_mfma_cheb<., true> in one pass over cur and out.
+struct S5Epilogue { int kind = 0; const double* cur = nullptr; const double* old = nullptr; double a = 1.0, b = 0.0; };
+
 template <bool TWO, bool LDSA>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+2)*/,
@@ -446,7 +454,8 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
                                                const double* __restrict__ frag_head = nullptr /*[chain][tau][S5_HEAD_DOUBLES]: per-chain head of the stream*/,
                                                int ntau = 0, int lds_tau = 0 /*LDSA: the operator class whose stream is staged (all groups must be of it)*/,
                                                int* __restrict__ queue = nullptr /*LDSA: [chain][16] group counters, zero at launch: persistent workgroups, one group per pull*/,
-                                               int spin_by_xcd = 1 /*LDSA: 1: even XCDs spin 0, odd spin 1 (collinear operators); 0: both spins on every XCD*/) {
+                                               int spin_by_xcd = 1 /*LDSA: 1: even XCDs spin 0, odd spin 1 (collinear operators); 0: both spins on every XCD*/,
+                                               S5Epilogue epi = S5Epilogue()) {
     extern __shared__ double s5_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -566,18 +575,57 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI
         // layout; the 4x4x4 result: row 16 + l4 -> l4 = 0: re, 1: im of m = 8
+        // Epilogue operands first, for several tiles at once (the three operand sets of the stream are dead: ~110 registers are free):
+        // two memory round trips per group instead of one per tile.  Padding atoms read the zero block; only their stores are skipped.
+        auto finish = [&](auto t0c, auto t1c) {
+            constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NT = T1 - T0;
+            size_t eo[NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int a = (t < 8) ? atom[t] : my_rem_atom;
-            if (a == zero_block) continue;
-            double* ob = out + (size_t)BLD * a + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1));
+            for (int i = 0; i < NT; ++i) { const int t = T0 + i; eo[i] = (size_t)BLD * ((t < 8) ? atom[t] : my_rem_atom) + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1)); }
+            s5_d2 ec[NT][2], ez[NT][2];
+            double ecr[NT], ezr[NT];
+            if (epi.kind) {
+                const double* cb = epi.cur + vo;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                s5_d2 v; v[0] = acc.m[t][2 * p]; v[1] = acc.m[t][2 * p + 1];
-                *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
+                for (int i = 0; i < NT; ++i) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) ec[i][p] = *reinterpret_cast<const s5_d2*>(cb + eo[i] + 36 * (4 * p + l4));
+                    ecr[i] = cb[eo[i] + 288 + (l4 & 1)];
+                }
+                if (epi.kind == 2) {
+                    const double* zb = epi.old + vo;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) ez[i][p] = *reinterpret_cast<const s5_d2*>(zb + eo[i] + 36 * (4 * p + l4));
+                        ezr[i] = zb[eo[i] + 288 + (l4 & 1)];
+                    }
+                }
             }
-            if (l4 < 2) ob[288 + l4] = acc.r[t];
-        }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = T0 + i;
+                const int a = (t < 8) ? atom[t] : my_rem_atom;
+                double* ob = out + eo[i];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    s5_d2 v; v[0] = acc.m[t][2 * p]; v[1] = acc.m[t][2 * p + 1];
+                    if (epi.kind) {
+                        v[0] = (v[0] - epi.b * ec[i][p][0]) / epi.a; v[1] = (v[1] - epi.b * ec[i][p][1]) / epi.a;
+                        if (epi.kind == 2) { v[0] = v[0] * 2.0 - ez[i][p][0]; v[1] = v[1] * 2.0 - ez[i][p][1]; }
+                    }
+                    if (a != zero_block) *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
+                }
+                double r = acc.r[t];
+                if (epi.kind) {
+                    r = (r - epi.b * ecr[i]) / epi.a;
+                    if (epi.kind == 2) r = r * 2.0 - ezr[i];
+                }
+                if (a != zero_block && l4 < 2) ob[288 + l4] = r;
+            }
+        };
+        finish(S5C<0>{}, S5C<5>{});
+        finish(S5C<5>{}, S5C<9>{});
     }
     }   // chains of this workgroup
 }

@@ -284,7 +284,9 @@ __global__ void k_uscheme_init(double2* Bmats, double* tabs, int ci) {
 // reductions are real 36x36 Gram matrices with the stacked rows as MFMA K dimension (same construction as k_mfma_adot);
 // partial[chain][workgroup][2][1296].
 // ======================================================================================================================
-template <bool FIRST>
+// FUSED: the element-wise step was done by the SpMM's epilogue (S5Epilogue): `out_all` already holds the new vector, only the Gram
+// matrices are formed here, in one pass over cur and out.
+template <bool FIRST, bool FUSED = false>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                const double* __restrict__ cur_all, const double* __restrict__ old_all,
                                                                double* __restrict__ out_all, double a, double b, double* partial) {
@@ -295,9 +297,9 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
     const int ngroups = CV.count_of(chain, level) / GROUP;
     const int* order = CV.order_of(chain, level);
     const size_t vo = (size_t)chain * CV.vstride;
-    const double* tv = tvec + vo;
+    const double* tv = FUSED ? nullptr : tvec + vo;
     const double* cu = cur_all + vo;
-    const double* ol = FIRST ? nullptr : old_all + vo;
+    const double* ol = (FIRST || FUSED) ? nullptr : old_all + vo;
     double* out = out_all + vo;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     GramAcc G1, G2;
@@ -308,16 +310,21 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
 #pragma unroll 2
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);
-            const double t0 = tv[rk.off + l15], t1 = tv[rk.off + 16 + l15], tr = tv[rk.off + 32 + l3];
             const double c0 = cu[rk.off + l15], c1 = cu[rk.off + 16 + l15], cr = cu[rk.off + 32 + l3];
-            double n0 = (t0 - b * c0) / a, n1 = (t1 - b * c1) / a, nr = (tr - b * cr) / a;
-            if (!FIRST) {
-                const double z0 = ol[rk.off + l15], z1 = ol[rk.off + 16 + l15], zr = ol[rk.off + 32 + l3];
-                n0 = n0 * 2.0 - z0; n1 = n1 * 2.0 - z1; nr = nr * 2.0 - zr;
-            }
-            if (rk.valid) {
-                out[rk.off + l15] = n0; out[rk.off + 16 + l15] = n1;
-                if (lg == 0) out[rk.off + 32 + l3] = nr;
+            double n0, n1, nr;
+            if (FUSED) {
+                n0 = out[rk.off + l15]; n1 = out[rk.off + 16 + l15]; nr = out[rk.off + 32 + l3];
+            } else {
+                const double t0 = tv[rk.off + l15], t1 = tv[rk.off + 16 + l15], tr = tv[rk.off + 32 + l3];
+                n0 = (t0 - b * c0) / a; n1 = (t1 - b * c1) / a; nr = (tr - b * cr) / a;
+                if (!FIRST) {
+                    const double z0 = ol[rk.off + l15], z1 = ol[rk.off + 16 + l15], zr = ol[rk.off + 32 + l3];
+                    n0 = n0 * 2.0 - z0; n1 = n1 * 2.0 - z1; nr = nr * 2.0 - zr;
+                }
+                if (rk.valid) {
+                    out[rk.off + l15] = n0; out[rk.off + 16 + l15] = n1;
+                    if (lg == 0) out[rk.off + 32 + l3] = nr;
+                }
             }
             if (FIRST) {          // G2 = psi0hat^T psi1hat
                 G2.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, n0, G2.t00, 0, 0, 0);

@@ -95,7 +95,7 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
@@ -354,8 +354,10 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "s5_cap")) h->opt_s5_cap = value;
     else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
     else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
+    else if (!strcmp(key, "cheb_fused")) h->opt_cheb_fused = value;
     else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
     else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
+    else if (!strcmp(key, "cheb_fused")) h->opt_cheb_fused = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -798,7 +800,7 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
 constexpr size_t S5_LDS_LIMIT = 160 * 1024;
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
-               const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0) {
+               const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0, S5Epilogue epi = S5Epilogue()) {
     const size_t lds_bytes = (size_t)op.ntr * S5_TRIPLE * sizeof(double);
     const int one = op.single_class(set);
     // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
@@ -829,9 +831,9 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
                 g2 = dim3(256, 1);
             }
         }
-        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd);
+        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
-        k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0);
+        k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0, nullptr, 1, epi);
     if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)
         h->n_hop_mfma_flop += (*h->cur_level_groups)[SD.level] * op.flops_per_group(set);
 }
@@ -1597,19 +1599,26 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
             if (mf_cheb) {
                 SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, lv_final, velems, CV.obase, nb};
                 const dim3 gl = level_grid(h, grid_mf, lv_final);
+                // k_spmm5 forms the new vector in its epilogue (dst = (H src - b src)/a [* 2 - p0]); k_mfma_cheb then only sums the Grams
+                const bool fused = (hoh || use_kp) && h->opt_cheb_fused;
+                S5Epilogue E;
+                if (fused) { E.kind = first ? 1 : 2; E.cur = src; E.old = first ? nullptr : p0; E.a = a; E.b = b; }
                 if (hoh) {
                     SD.level = 2 * t - 1;
                     launch_s5<false>(h, s5_grid(h, grid_mf, 2 * t - 1), SD, CV.order, CV.cum, P.iz, h->s5_op, 0, src, hps);
                     SD.level = lv_final;
-                    launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 1, hps, tmp, src);
-                } else if (use_kp) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 0, src, tmp);
+                    launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 1, hps, fused ? dst : tmp, src, nullptr, 0, E);
+                } else if (use_kp) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, h->s5_op, 0, src, fused ? dst : tmp, nullptr, nullptr, 0, E);
                 else { rc = launch_spmm(h, SD, CV, P, 0, src, tmp, grid_mf); if (rc) return rc; }
                 hipEvent_t e1 = next_event(h);
                 hop_ev.emplace_back(e0, e1);
                 h->n_hop_launch += hoh ? 2 : 1;
                 double* gp = h->d_partial.as<double>();
                 if (red_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); red_pending = false; }   // gp is free again
-                if (first) k_mfma_cheb<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
+                if (fused) {
+                    if (first) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
+                    else k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
+                } else if (first) k_mfma_cheb<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
                 else k_mfma_cheb<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 hipStream_t rs = h->stream;
                 if (side) {
