@@ -1769,16 +1769,21 @@ struct KuboCtx {
     double *hps, *p1, *p2;      // temporaries of the two-pass products
 };
 
-void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double* in, double* out, const double* in2) {
+void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double* in, double* out, const double* in2, S5Epilogue epi = S5Epilogue()) {
     rsrec_t* h = K.h;
-    if (in2) launch_s5<true>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, in2);
-    else launch_s5<false>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out);
+    if (in2) launch_s5<true>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, in2, nullptr, 0, epi);
+    else launch_s5<false>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, nullptr, nullptr, 0, epi);
 }
-// out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift)
-void kubo_apply_h(const KuboCtx& K, const double* in, double* out) {
-    if (!K.h->hoh) { kubo_spmm(K, K.h->s5_op, 0, in, out, nullptr); return; }
+// out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift), or with an epilogue the whole Chebyshev
+// step  out = (H in - b in)/a  [* 2 - old]  (their scale-and-shift :968-970 and the caller's recurrence :1132-1136) in the same kernel
+void kubo_apply_h(const KuboCtx& K, const double* in, double* out, S5Epilogue epi = S5Epilogue()) {
+    if (!K.h->hoh) { kubo_spmm(K, K.h->s5_op, 0, in, out, nullptr, epi); return; }
     kubo_spmm(K, K.h->s5_op, 0, in, K.hps, nullptr);
-    kubo_spmm(K, K.h->s5_op, 1, K.hps, out, in);
+    kubo_spmm(K, K.h->s5_op, 1, K.hps, out, in, epi);
+}
+S5Epilogue cheb_epilogue(bool first, const double* cur, const double* old, double a, double b) {
+    S5Epilogue E; E.kind = first ? 1 : 2; E.cur = cur; E.old = first ? nullptr : old; E.a = a; E.b = b;
+    return E;
 }
 // out = V in   (velo_vec_matmul :587 / velo_hoh_vec_matmul :656)
 void kubo_apply_v(const KuboCtx& K, const Spmm5Operator& vop, const double* in, double* out) {
@@ -1833,7 +1838,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     HIPCK(h, hipMemsetAsync(work.p, 0, 11 * velems * 8, h->stream));            // block kk of every vector stays the zero block
     double* V[11];
     for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * velems;
-    double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3], *t = V[4], *right = V[5];
+    double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3], *right = V[5];
     HIPCK(h, h->d_seed.reserve((size_t)nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)nseed * sizeof(double2)));
     // region list: all atoms (every launch of this path runs over the whole lattice)
@@ -1850,7 +1855,6 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     K.grid = s5_grid(h, dim3(256, 1), 0);
     K.iz = h->d_iz.as<int>();
     K.hps = V[6]; K.p1 = V[7]; K.p2 = V[8];
-    const int cgrid = (int)std::min<size_t>(4096, (nd + 255) / 256);
     const int m_rows = cond_ll * NB;
     std::vector<double> mu_chunk((size_t)m_rows * nchunk * NB * 2);
     hipEvent_t e_begin = next_event(h);
@@ -1873,11 +1877,9 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         for (int m = 0; m < cond_ll; ++m) {
             if (m == 1) {
                 std::swap(x0, x1);                                        // w0 = w1
-                kubo_apply_h(K, x0, t);
-                k_cheb_combine<true><<<cgrid, 256, 0, h->stream>>>(nd, t, x0, nullptr, x1, a, b);
+                kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
             } else if (m > 1) {
-                kubo_apply_h(K, x1, t);
-                k_cheb_combine<false><<<cgrid, 256, 0, h->stream>>>(nd, t, x1, x0, x2, a, b);
+                kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
                 double* o = x0; x0 = x1; x1 = x2; x2 = o;                 // w0 = w1, w1 = w2
             }
             k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(x1), Lm.as<double2>(), ld, m * NB);
@@ -1888,11 +1890,9 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         for (int n = 0; n < cond_ll; ++n) {
             if (n == 1) {
                 std::swap(x0, x1);
-                kubo_apply_h(K, x0, t);
-                k_cheb_combine<true><<<cgrid, 256, 0, h->stream>>>(nd, t, x0, nullptr, x1, a, b);
+                kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
             } else if (n > 1) {
-                kubo_apply_h(K, x1, t);
-                k_cheb_combine<false><<<cgrid, 256, 0, h->stream>>>(nd, t, x1, x0, x2, a, b);
+                kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
                 double* o = x0; x0 = x1; x1 = x2; x2 = o;
             }
             kubo_apply_v(K, h->kubo_op[0], x1, right);

@@ -59,6 +59,7 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
     assert "fatal" not in log.lower(), log[-3000:]                      # tests/run_test.py:119-131
     if "exe" in case:
         assert "compute_moments_stochastic wall time" in log
+        print("\n".join(l for l in log.splitlines() if "compute_moments_stochastic wall time" in l))
     elif "'block'" in str(case["patch"]):
         # block recursions: the Green function (green%bgreen) also ran on the GPU (fortran/green_gpu.f90); its timer region is
         # listed in the reference's own timing report
