@@ -104,14 +104,6 @@ def tilt_spin_frame(st, theta):
     return out
 
 
-def scrubbed_env(extra):
-    """Environment for the CPU-baseline child: nothing of a profiler's preload may reach it (the child must not initialise the GPU)."""
-    env = {k: v for k, v in os.environ.items()
-           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX", "ROCTRACER"))}
-    env.update(extra)
-    return env
-
-
 def cpu_quota():
     """CPU bandwidth limit of this container (cgroup v2 cpu.max / v1 cfs quota), in CPUs; None if unlimited/unknown."""
     try:
@@ -135,7 +127,6 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
     for this leg, the compiled reference is the stronger baseline and the task statement allows it as kind "reference").
     Fallback: the C restatement in oracle/ ("port")."""
     import numpy as np
-    import resource
     from rslmtoasa_amd.lattice import active_region_sizes, spread_sites
     napply = lld - 1 if recur == "block" else lld + 1
     sizes = [1] + active_region_sizes(nn, 1, (2 if hoh else 1) * napply)
@@ -147,9 +138,9 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
         mults = sum(nb * (sizes[2 * t] + sizes[2 * t + 1]) + 2 * sizes[2 * t] for t in range(napply))
         atom_steps = sum(sizes[2 * t + 2] for t in range(napply))
     flop = FLOP_PER_BLOCK_MULT * (mults + POST_FLOP_BLOCKS[recur] * atom_steps)
+    from rslmtoasa_amd._proc import run_with_unlimited_stack, under_profiler
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_kernel.x")
-    profiled = any(k.startswith(("ROCP", "ROCPROF")) or k == "HSA_TOOLS_LIB" for k in os.environ)
-    if profiled:
+    if under_profiler():
         print("cpu_baseline skipped: running under a profiler (its preload must not reach a child process)", file=sys.stderr)
         return None
     kk = nn.shape[0]
@@ -164,11 +155,7 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
             if hoh:
                 p.update(eeo=st["eeo"], enim=st["enim"])
             fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
-            env = scrubbed_env(dict(OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G"))
-
-            def unlimited_stack():      # the reference's automatic arrays overflow the default stack
-                resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
-            r = subprocess.run([exe], cwd=scratch, env=env, capture_output=True, text=True, timeout=900, preexec_fn=unlimited_stack)
+            r = run_with_unlimited_stack([exe], cwd=scratch, env={"OMP_NUM_THREADS": str(threads)}, timeout=900)   # scrubbed environment, no shell hop
             t = None
             for line in r.stdout.splitlines():
                 if "recursion wall time" in line:
@@ -327,7 +314,8 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    tm_acc = {"hop_ms": 0.0, "hop_launches": 0.0, "atom_steps": 0.0, "block_multiplies": 0.0, "total_ms": 0.0, "host_ms": 0.0, "hop_mfma_flop": 0.0}
+    tm_acc = {"hop_ms": 0.0, "hop_launches": 0.0, "atom_steps": 0.0, "block_multiplies": 0.0, "total_ms": 0.0, "host_ms": 0.0, "hop_mfma_flop": 0.0,
+              "hop_required_flop": 0.0}
     for _ in range(args.steps):
         step()
         tm = rec.timing()
@@ -354,14 +342,22 @@ def main():
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + POST_FLOP_BLOCKS[args.recur] * tm_acc["atom_steps"])
         flop_total = flop_rank * world
         bytes_total = BYTES_PER_ATOM_STEP[args.recur] * tm_acc["atom_steps"] * world
-        # dominant kernel = H|psi>: the block SpMM, 46656 flop per block multiply (+ 46656 per atom-step when the kernel
-        # also forms the A_n partial: VALU kernels and the fused MFMA variant)
+        # dominant kernel = H|psi>: the block SpMM.  Two flop counts:
+        #   algorithmic: 46656 per block multiply = the reference's zgemm on full 18x18 blocks (`value` and the CPU baseline use it)
+        #   required:    what the operator's block structure needs -- 23328 per spin-diagonal block (the hopping blocks of a collinear
+        #                magnet, hamiltonian.f90:1553-1617), 46656 per spin-mixing block (rsrec_get_timing out[9]).  Roofline fractions
+        #                are quoted in REQUIRED flops: a kernel cannot exceed the pipe's peak in them.
+        # (+ 46656 per atom-step when the kernel also forms the A_n partial: VALU kernels)
         fuses = tm.get("hop_fuses_a", 1.0) and args.recur == "block"
         hop_flop = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + (tm_acc["atom_steps"] if fuses else 0.0))
+        hop_req = tm_acc["hop_required_flop"] + (FLOP_PER_BLOCK_MULT * tm_acc["atom_steps"] if fuses else 0.0)
         hop_s = tm_acc["hop_ms"] * 1e-3
-        achieved = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
+        achieved_alg = hop_flop / hop_s * 1e-12 if hop_s > 0 else 0.0
+        achieved = hop_req / hop_s * 1e-12 if hop_s > 0 else 0.0
         executed = tm_acc["hop_mfma_flop"] / hop_s * 1e-12 if hop_s > 0 else 0.0   # matrix flops the kernel issued (tile padding included)
-        step_tflops = flop_total / world / elapsed * 1e-12          # per-GPU whole-level rate
+        step_tflops = flop_total / world / elapsed * 1e-12          # per-GPU whole-level rate, algorithmic count
+        req_rank = hop_req + FLOP_PER_BLOCK_MULT * POST_FLOP_BLOCKS[args.recur] * tm_acc["atom_steps"]     # whole level, required count (post-hop blocks are dense)
+        step_req_tflops = req_rank / elapsed * 1e-12
         kernel = "k_spmm5"
         traffic, traffic_src = (None, None) if tuned else profiled_traffic(wl_key, kernel)
         out = {
@@ -391,13 +387,15 @@ def main():
             # roofline of the dominant kernel (frac = frac_kernel) and of the whole recursion level (frac_step): the headline `value`
             # divided by the same peak -- the whole-level number is the one to compare runs by
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "frac_kernel": achieved / FP64_PEAK_TFLOPS, "frac_step": step_tflops / FP64_PEAK_TFLOPS,
+                         "frac_kernel": achieved / FP64_PEAK_TFLOPS, "frac_step": step_req_tflops / FP64_PEAK_TFLOPS,
+                         "frac_algorithmic": achieved_alg / FP64_PEAK_TFLOPS, "frac_step_algorithmic": step_tflops / FP64_PEAK_TFLOPS,
+                         "achieved_algorithmic": achieved_alg, "required_per_algorithmic": hop_req / hop_flop if hop_flop > 0 else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel + " (H|psi> block SpMM, FP64 MFMA)" if not fuses else "H|psi> (hop)", "launches": tm_acc["hop_launches"],
                          "avg_launch_ms": tm_acc["hop_ms"] / max(tm_acc["hop_launches"], 1),
-                         "flops_counted": ("algorithmic = 46656 per block multiply (SURVEY 8d: the reference's zgemm on full 18x18 blocks), structural zeros of "
-                                           "spin-diagonal blocks included -- the kernel skips them, so this rate can exceed the pipe's peak") if not args.spin_mixing else
-                                          "algorithmic = 46656 per block multiply; spin-mixing blocks: nothing skipped",
+                         "flops_counted": ("required by the operator's block structure: 23328 per spin-diagonal block multiply, 46656 per spin-mixing one "
+                                           "(frac, frac_kernel, frac_step); *_algorithmic = the reference's zgemm count, 46656 per block multiply (SURVEY 8d), "
+                                           "which includes multiplications by structural zeros and can therefore exceed the peak"),
                          # what the matrix pipe actually did: MFMA flops issued by the kernel (18 -> 20 row padding of the tiles included)
                          "executed": {"achieved": executed, "frac": executed / FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "executed_per_algorithmic": tm_acc["hop_mfma_flop"] / hop_flop if hop_flop > 0 else None},

@@ -26,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle import fixture_io as fio  # noqa: E402
+from rslmtoasa_amd._proc import run_with_unlimited_stack  # noqa: E402
 
 REF = os.environ.get("RSREC_REFERENCE", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -88,10 +89,9 @@ def patch_namelist(text, patch):
     return text
 
 
-def run_env(threads=8):
-    env = dict(os.environ)
-    env.update(OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G")
-    return env
+def run_ref(exe, cwd, threads=8, timeout=None):
+    """One of the compiled-reference programs of oracle/_ref, with the unlimited stack its automatic arrays need (no shell hop)."""
+    return run_with_unlimited_stack([exe], cwd=cwd, env={"OMP_NUM_THREADS": str(threads)}, timeout=timeout)
 
 
 def run_case(name):
@@ -109,8 +109,7 @@ def run_case(name):
             q = os.path.join(scratch, fn)
             t = re.sub(r"(?im)^(\s*mom\s*=\s*)[^\n]*", lambda mm: mm.group(1) + "%.16g, %.16g, %.16g" % mom, open(q).read(), count=1)
             open(q, "w").write(t)
-        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_fixture.x")
-        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
+        r = run_ref(os.path.join(HERE, "_ref", "dump_fixture.x"), scratch)
         if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "fixture.bin")):
             print(r.stdout[-3000:], r.stderr[-3000:])
             raise RuntimeError("dump_fixture failed for " + name)
@@ -173,8 +172,7 @@ def run_green_case(name):
         p = os.path.join(scratch, "input.nml")
         txt = patch_namelist(open(p).read(), patch)
         open(p, "w").write(txt)
-        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_fixture.x")
-        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
+        r = run_ref(os.path.join(HERE, "_ref", "dump_fixture.x"), scratch)
         if r.returncode != 0:
             print(r.stdout[-3000:], r.stderr[-3000:])
             raise RuntimeError("dump_fixture failed for " + name)
@@ -230,8 +228,7 @@ def supercell_case(name, dims, lld, kind, hoh, nsites, stencil="bccFe_nsp2_block
     scratch = tempfile.mkdtemp(prefix="rsrec_sc_%s_" % name)
     try:
         fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
-        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "ref_kernel.x")
-        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(threads), capture_output=True, text=True)
+        r = run_ref(os.path.join(HERE, "_ref", "ref_kernel.x"), scratch, threads)
         if r.returncode != 0:
             print(r.stdout[-3000:], r.stderr[-3000:])
             raise RuntimeError("ref_kernel failed for " + name)
@@ -296,8 +293,7 @@ def run_kubo_case(name):
         txt = "\n".join(l for l in txt.splitlines() if not re.match(r"\s*(js_alpha|cond_type)\s*=", l)) + "\n"
         txt = patch_namelist(txt, patch)
         open(p, "w").write(txt)
-        cmd = "ulimit -s unlimited; exec %s" % os.path.join(HERE, "_ref", "dump_kubo.x")
-        r = subprocess.run(["bash", "-c", cmd], cwd=scratch, env=run_env(), capture_output=True, text=True)
+        r = run_ref(os.path.join(HERE, "_ref", "dump_kubo.x"), scratch)
         if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "kubo.bin")):
             print(r.stdout[-3000:], r.stderr[-3000:])
             raise RuntimeError("dump_kubo failed for " + name)

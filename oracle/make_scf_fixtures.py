@@ -65,10 +65,10 @@ def generated_cases():
     (oracle/_ref/rslmto_ref.x, oracle/build_ref.sh) on a variant of one of its cases.
     Generated_bulk_bccFe_nsp4_local_axis: hamiltonian%local_axis = T with the moment tilted to (0.6, 0, 0.8): recur_b re-rotates
     every Hamiltonian block into the site's spin frame before its chain (recursion.f90:1830-1832)."""
-    import subprocess
     import sys
     import tempfile
     sys.path.insert(0, ROOT)
+    from rslmtoasa_amd._proc import run_with_unlimited_stack
     from oracle.make_fixtures import patch_namelist
     exe = os.path.join(ROOT, "oracle", "_ref", "rslmto_ref.x")
     out = {}
@@ -90,8 +90,7 @@ def generated_cases():
         p = os.path.join(work, "input.nml")
         txt_in = patch_namelist(open(p).read(), patch)
         open(p, "w").write(txt_in)
-        env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
-        r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=work, env=env, capture_output=True, text=True, timeout=3000)
+        r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8"}, timeout=3000)
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
         txt = open(os.path.join(work, "Fe_out.nml")).read()
 
@@ -113,10 +112,10 @@ def generated_cases():
 
 def _run_reference(exe, dst, patch, timeout=3000):
     """Run the compiled reference in a scratch copy of `dst` (the committed input files) with `patch` applied; returns the work dir."""
-    import subprocess
     import sys
     import tempfile
     sys.path.insert(0, ROOT)
+    from rslmtoasa_amd._proc import run_with_unlimited_stack
     from oracle.make_fixtures import patch_namelist
     work = tempfile.mkdtemp(prefix="rsrec_scf_gen_")
     for fn in os.listdir(dst):
@@ -124,8 +123,7 @@ def _run_reference(exe, dst, patch, timeout=3000):
     p = os.path.join(work, "input.nml")
     txt = patch_namelist(open(p).read(), patch)
     open(p, "w").write(txt)
-    env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
-    r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec " + exe], cwd=work, env=env, capture_output=True, text=True, timeout=timeout)
+    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8"}, timeout=timeout)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     return work
 

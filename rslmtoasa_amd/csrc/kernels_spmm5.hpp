@@ -77,6 +77,7 @@ struct Spmm5Operator {
     struct Head { std::vector<double> blk; int flip = 0; bool valid = false; };
     std::vector<Head> head_main;   // [set][tau]: first regular entry of the schedule (its first two orbitals share triple 1 with the extra entries)
     std::vector<int> ksteps;       // [set][tau]: MFMA k-steps a wave runs per group (X, Y steps: 2, Z steps: 1)
+    std::vector<signed char> mixing;   // [set][tau][nslots + 1]: -1 absent, 0 spin-diagonal block (one quadrant pair: 23 328 flop), 1 spin-mixing (46 656 flop)
 
     void release() {
         if (d_frag) (void)hipFree(d_frag);
@@ -140,6 +141,9 @@ struct Spmm5Operator {
         std::vector<int> meta((size_t)nset * ntau * META, 0);
         head_main.assign((size_t)nset * ntau, Head());
         ksteps.assign((size_t)nset * ntau, 0);
+        mixing.assign((size_t)nset * ntau * nfs, -1);
+        for (size_t q = 0; q < mixing.size(); ++q)
+            if (blk[q]) mixing[q] = Spmm4Operator::pattern_of(blk[q]) == 0 ? 1 : 0;
         int maxent = 0;
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
@@ -240,6 +244,13 @@ struct Spmm5Operator {
     }
     // matrix flops one group of 8 atoms costs in set `set` (both spin waves; class of the last atom type -- the bulk atoms): per k-step
     // nine tiles of one 16x16x4 and one 4x4x4 (4 blocks) MFMA
+    // flops the block structure REQUIRES for one multiplication by block (set, tau, slot): a spin-diagonal block (hopping block of a
+    // collinear magnet, hamiltonian.f90:1553-1617) is two 9x9 complex quadrants = half of the reference's 18x18x18 zgemm (recursion.f90:1618)
+    double required_flops(int set, int tau, int slot) const {
+        const size_t q = ((size_t)set * ntau + tau) * (nslots + 1) + slot;
+        if (q >= mixing.size() || mixing[q] < 0) return 0.0;
+        return mixing[q] ? 46656.0 : 23328.0;
+    }
     double flops_per_group(int set) const { return ksteps.empty() ? 0.0 : 2.0 * ksteps[(size_t)set * ntau + ntau - 1] * 9.0 * (2.0 * 16 * 16 * 4 + 2.0 * 4 * 4 * 4 * 4); }
     const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * 2 * ntr * S5_TRIPLE; }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }

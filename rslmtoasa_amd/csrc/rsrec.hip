@@ -83,6 +83,10 @@ struct rsrec_handle {
     Spmm5Operator s5_op;
     DevBuf d_s5queue;            // group counters of the persistent k_spmm5 form
     int s5_built = 0;
+    size_t s5_lds_limit = (size_t)-1;   // LDS a k_spmm5 workgroup may ask for on THIS handle's device ((size_t)-1: not asked yet; hipFuncSetAttribute is per device)
+    int n_cu = 0;                       // compute units of the device (size of the persistent launches)
+    bool s4_attr = false;               // k_spmm4's and k_terminator's LDS opt-ins, per handle for the same reason
+    size_t term_attr_lds = 0;
     std::vector<double> host_ee, host_lsham, host_eeo, host_enim, host_hall, host_hallo;   // operator arrays as last set (Kubo operator tables; local-axis runs)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
@@ -99,6 +103,7 @@ struct rsrec_handle {
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
+    double n_req_flop = 0;    // flops of H|psi> the operator's block structure requires (spin-diagonal blocks: half a zgemm), see required_hop_flops
     int hop_fuses_a = 1;      // 1: the timed H|psi> kernel also forms pmn and the A_n partial (VALU path); 0: pure SpMM (MFMA path)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -111,6 +116,7 @@ struct rsrec_handle {
         DevBuf order, cum;
         std::vector<int> level_max;     // per level: largest active-atom count over the chains of this entry
         std::vector<double> level_groups;   // per level: groups of 8 atoms (padding included) summed over the chains
+        std::vector<double> mult_hist;      // [pass 0/1][tau][nslots + 1]: block multiplications of the call by (pass, operator class, slot), summed over the chains
     };
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
@@ -118,6 +124,7 @@ struct rsrec_handle {
     const int* cur_cum = nullptr;     // [nrows][nlev] counts, followed by [nrows][nlev] list offsets
     const std::vector<int>* cur_level_max = nullptr;
     const std::vector<double>* cur_level_groups = nullptr;
+    const std::vector<double>* cur_mult_hist = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
     // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root)
@@ -309,6 +316,7 @@ extern "C" int rsrec_create(rsrec_t** out, int device) {
     rsrec_t* h = new rsrec_handle();
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RSREC_ERR_DEVICE; }
+    if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     *out = h;
     return RSREC_OK;
 }
@@ -365,8 +373,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
 
 extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
     if (!h || !out) return RSREC_ERR_ARG;
-    const double v[9] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop};
-    for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
+    const double v[10] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop,
+                          h->n_req_flop};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
     return RSREC_OK;
 }
 
@@ -600,11 +609,15 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
             h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
+            h->cur_mult_hist = &e->mult_hist;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
     std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)2 * nb * nlev, 0);
     std::vector<double> as(nb, 0.0), bm(nb, 0.0);
+    const int ntau_h = h->nmax + h->ntype, nfs_h = h->nslots + 1;
+    const size_t hist_n = (size_t)2 * ntau_h * nfs_h;
+    std::vector<double> hist((size_t)nb * hist_n, 0.0);
     auto tau = [&](int i) { return i < h->nmax ? i : h->nmax + h->iz0[i]; };
     const std::vector<unsigned>& key = h->spatial_key;
     auto before = [&](int x, int y) {                       // operator class first (groups must be homogeneous), then position
@@ -656,7 +669,6 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         for (int t = 1; t <= napply; ++t) {
             const int lv_after = two_pass ? 2 * t : t;
             a_s += R.cum[std::min(lv_after, nlev - 1)];
-            if (two_pass) b_m += 2.0 * R.cum[2 * (t - 1)];   // enim*psi and lsham*psi on-site products (hop_b_hoh :1437-1438)
         }
         std::vector<int> lev_of(kk, -1);
         {
@@ -666,20 +678,29 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
                 lev_of[R.order[q]] = lv;
             }
         }
-        std::vector<double> uses(nlev + 1, 0.0);   // uses[d] = number of applications in which a source at distance d is active
-        for (int d = 0; d < nlev; ++d) {
-            double u = 0.0;
+        // uses1[d] / uses2[d]: applications whose first / second (hoh) pass sees a source at distance d inside the region
+        std::vector<double> uses1(nlev + 1, 0.0), uses2(nlev + 1, 0.0);
+        for (int d = 0; d < nlev; ++d)
             for (int t = 1; t <= napply; ++t) {
-                if (!two_pass) { if (d <= t - 1) u += 1.0; }
-                else { if (d <= 2 * (t - 1)) u += 1.0; if (d <= 2 * t - 1) u += 1.0; }
+                if (!two_pass) { if (d <= t - 1) uses1[d] += 1.0; }
+                else { if (d <= 2 * (t - 1)) uses1[d] += 1.0; if (d <= 2 * t - 1) uses2[d] += 1.0; }
             }
-            uses[d] = u;
+        // one multiplication per (target atom i, slot s) whose source nbr(i, s) is active (hop_b :1576-1625), kept by (pass, operator class
+        // of the target, slot): the reference's count is their sum, the flops the block structure requires weigh them by block class
+        double* H = hist.data() + (size_t)c * hist_n;
+        const int ns = h->nslots;
+        for (int i = 0; i < kk; ++i) {
+            const int ti = tau(i);
+            for (int s = 0; s < ns; ++s) {
+                const int n = h->nbr[(size_t)i * ns + s];
+                if (n < 0 || lev_of[n] < 0) continue;
+                H[(size_t)ti * nfs_h + s] += uses1[lev_of[n]];
+                if (two_pass) H[((size_t)ntau_h + ti) * nfs_h + s] += uses2[lev_of[n]];
+            }
+            if (two_pass && lev_of[i] >= 0) H[((size_t)ntau_h + ti) * nfs_h + ns] += uses1[lev_of[i]];   // e_nu psi + l.s psi on-site (:1437-1438), one merged block here
         }
-        for (int n = 0; n < kk; ++n) {
-            if (lev_of[n] < 0) continue;
-            const int fan = 1 + (h->radj_ptr[n + 1] - h->radj_ptr[n]);   // on-site + every atom that lists n as a neighbour
-            b_m += uses[lev_of[n]] * fan;
-        }
+        for (size_t q = 0; q < hist_n; ++q) b_m += H[q];
+        if (two_pass) for (int t2 = 0; t2 < ntau_h; ++t2) b_m += H[((size_t)ntau_h + t2) * nfs_h + ns];       // the reference multiplies enim and lsham separately
         as[c] = a_s; bm[c] = b_m;
     };
     {
@@ -706,6 +727,9 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     e->seeds.assign(seeds0, seeds0 + (size_t)nb * nseed);
     e->nlev = nlev; e->napply = napply; e->flags = flags; e->epoch = h->lattice_epoch; e->ostride = ostride;
     e->atom_steps = as_sum; e->block_mults = bm_sum;
+    e->mult_hist.assign(hist_n, 0.0);
+    for (int c = 0; c < nb; ++c)
+        for (size_t q = 0; q < hist_n; ++q) e->mult_hist[q] += hist[(size_t)c * hist_n + q];
     h->region_cache.push_back(e);
     HIPCK(h, e->order.reserve(order.size() * 4));
     HIPCK(h, e->cum.reserve(cum.size() * 4));
@@ -720,12 +744,33 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             e->level_groups[l] += cum[(size_t)c * nlev + l] / GROUP;
         }
     h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
+    h->cur_mult_hist = &e->mult_hist;
     return RSREC_OK;
+}
+
+// Flops of the H|psi> applications of the current region entry that the operator's block structure requires: the reference multiplies
+// full 18x18 blocks (zgemm, recursion.f90:1618: 46 656 flop each), but the hopping blocks of a collinear magnet are spin-diagonal
+// (hamiltonian.f90:1553-1617) and need half of that.  This -- not the reference's count -- is what a roofline fraction is measured in.
+double required_hop_flops(const rsrec_t* h, const Spmm5Operator& op) {
+    if (!h->cur_mult_hist) return 0.0;
+    const int ntau = h->nmax + h->ntype, nfs = h->nslots + 1;
+    const std::vector<double>& H = *h->cur_mult_hist;
+    if (H.size() != (size_t)2 * ntau * nfs) return 0.0;
+    double f = 0.0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int t = 0; t < ntau; ++t)
+            for (int s = 0; s < nfs; ++s) {
+                const double n = H[((size_t)pass * ntau + t) * nfs + s];
+                if (n == 0.0) continue;
+                const double w = (op.mixing.empty() || op.ntau != ntau || op.nslots != h->nslots) ? 46656.0 : op.required_flops(pass, t, s);
+                f += n * (w > 0.0 ? w : 46656.0);
+            }
+    return f;
 }
 
 void reset_timing(rsrec_t* h) {
     h->t_total_ms = h->t_hop_ms = h->t_rest_ms = h->t_host_ms = 0;
-    h->n_hop_launch = h->n_atom_steps = h->n_block_mult = h->n_hop_mfma_flop = 0;
+    h->n_hop_launch = h->n_atom_steps = h->n_block_mult = h->n_hop_mfma_flop = h->n_req_flop = 0;
     h->ev_used = 0;
 }
 
@@ -805,30 +850,32 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
     const int one = op.single_class(set);
     // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
     const bool want = h->opt_s5_lds >= 1;
-    // LDS a workgroup may ask for: what the device grants on request (160 KB on MI355X), asked for once per process
-    static size_t lds_limit = (size_t)-1;
-    if (lds_limit == (size_t)-1) {
+    // LDS a workgroup may ask for: what the device grants on request (160 KB on MI355X); asked for once per handle, i.e. per device --
+    // the attribute is a property of the (function, device) pair, a second handle on another GPU of the process needs its own opt-in
+    if (h->s5_lds_limit == (size_t)-1) {
         int optin = 0;
-        lds_limit = 0;
+        h->s5_lds_limit = 0;
         if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, h->device) == hipSuccess && optin > 64 * 1024) {
             const int ask = (int)std::min<size_t>((size_t)optin, S5_LDS_LIMIT);
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
-                lds_limit = (size_t)ask;
+                h->s5_lds_limit = (size_t)ask;
         }
         (void)hipGetLastError();
     }
+    const size_t lds_limit = h->s5_lds_limit;
     if (want && one >= 0 && !extra && lds_bytes <= lds_limit) {
         const int spin_by_xcd = op.spin_mixing ? 0 : 1;
         const unsigned row = spin_by_xcd ? 8 : 16;
         dim3 g2(std::max(row, (grid.x + row - 1) / row * row), grid.y);
         int* queue = nullptr;
-        if ((h->opt_s5_queue == 1 && grid.x >= 256) || h->opt_s5_queue >= 2) {
+        const unsigned ncu = (unsigned)std::max(16, h->n_cu / 16 * 16);     // whole rows of 8 / 16 workgroups (the kernel's XCD mapping)
+        if ((h->opt_s5_queue == 1 && grid.x >= ncu) || h->opt_s5_queue >= 2) {
             // persistent form: one workgroup per CU for the whole launch, groups from per-(chain, XCD[, spin]) counters
             if (h->d_s5queue.reserve((size_t)SD.nchains * 16 * sizeof(int)) == hipSuccess &&
                 hipMemsetAsync(h->d_s5queue.p, 0, (size_t)SD.nchains * 16 * sizeof(int), h->stream) == hipSuccess) {
                 queue = h->d_s5queue.as<int>();
-                g2 = dim3(256, 1);
+                g2 = dim3(ncu, 1);
             }
         }
         k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
@@ -843,10 +890,9 @@ bool spmm4_usable(const rsrec_t* h) { return h->s4_built_split && (size_t)(h->kk
 
 // small-launch SpMM on LayoutRM vectors: out = sum_slots H_slot in_nbr, four waves share one group of atoms (k_spmm4<4>)
 int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
-    static bool attr = false;
-    if (!attr) {
+    if (!h->s4_attr) {
         HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS_BYTES));
-        attr = true;
+        h->s4_attr = true;
     }
     // one group per workgroup at a time: 4x as many workgroups keep the same number of groups in flight per launch
     dim3 g4(std::min<unsigned>(grid_mf.x * 4, 1024), grid_mf.y);
@@ -928,6 +974,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         int ostride = kk;
         rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, nsteps, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
+        h->n_req_flop += required_hop_flops(h, OP);
         XFER(xfer_h2d(h, h->d_seed.p, seeds0.data(), seeds0.size() * 4));
         XFER(xfer_h2d(h, h->d_seedcoef.p, coef.data(), coef.size() * 8));
         const double* la_extra = nullptr;
@@ -1351,10 +1398,9 @@ int launch_terminator(rsrec_t* h, int n, int lld, const double2* d_ab, const dou
     while (T > 8 && (size_t)2 * lld * T * sizeof(double) > (size_t)128 * 1024) T >>= 1;
     const size_t lds = (size_t)2 * lld * T * sizeof(double);
     if (lds > (size_t)150 * 1024) return fail(h, RSREC_ERR_ARG, "terminator: lld = %d too deep for the LDS staging", lld);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    if (lds > h->term_attr_lds) {
         HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_terminator), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
+        h->term_attr_lds = lds;
     }
     k_terminator<<<dim3((BLK + T - 1) / T, n), T, lds, h->stream>>>(lld, d_ab, d_bs, d_ainf, d_binf);
     HIPCK(h, hipGetLastError());
@@ -1568,6 +1614,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         int ostride = kk;
         rc = upload_regions(h, seeds0.data(), nb, nseed, nlev, napply, hoh, MFMA, ostride, h->n_atom_steps, h->n_block_mult);
         if (rc) return rc;
+        h->n_req_flop += required_hop_flops(h, h->s5_op);
         XFER(xfer_h2d(h, h->d_seed.p, seeds0.data(), seeds0.size() * 4));
         XFER(xfer_h2d(h, h->d_seedcoef.p, coef.data(), coef.size() * 8));
         HIPCK(h, hipStreamSynchronize(h->stream));

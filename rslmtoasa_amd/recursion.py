@@ -128,9 +128,9 @@ class Recursion:
 
 
     def timing(self):
-        out = (C.c_double * 9)()
-        self._L.rsrec_get_timing(self._h, out, 9)
-        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a", "hop_mfma_flop")
+        out = (C.c_double * 10)()
+        self._L.rsrec_get_timing(self._h, out, 10)
+        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a", "hop_mfma_flop", "hop_required_flop")
         return dict(zip(keys, list(out)))
 
     # -- state (restore_to_default, recursion.f90:3713-3825) --------------------------------------------

@@ -14,6 +14,7 @@ import subprocess
 import pytest
 
 from oracle.make_fixtures import patch_namelist
+from rslmtoasa_amd._proc import run_with_unlimited_stack
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCF = os.path.join(ROOT, "tests", "golden", "scf")
@@ -52,8 +53,7 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
     shutil.copytree(os.path.join(SCF, case["inputs"]), work)
     inp = work / "input.nml"
     inp.write_text(patch_namelist(inp.read_text(), case["patch"]))
-    env = dict(os.environ, OMP_NUM_THREADS="8", OMP_STACKSIZE="1G")
-    r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec %s" % exe], cwd=work, env=env, capture_output=True, text=True, timeout=1500)
+    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8"}, timeout=1500, scrub=False)   # the child drives the GPU itself
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     assert "fatal" not in log.lower(), log[-3000:]                      # tests/run_test.py:119-131

@@ -2,7 +2,7 @@
 reference's own all-pairs search, through the reference's whole pre-processing (build_data, bravais, build_surf_full,
 newclu, structb): the resulting lattice%nn table and the `map` / `clust` files must be byte-identical.
 
-CPU only.  oracle/_ref/nncal_check.x (fortran/nncal_check.f90 + the compiled reference modules, fortran/build.sh) runs one
+CPU only.  oracle/_ref/nncal_check.x (tests/fortran/nncal_check.f90 + the compiled reference modules, fortran/build.sh) runs one
 mode per process; inputs are the reference's test cases held as data under tests/golden/scf/inputs."""
 import filecmp
 import os
@@ -12,6 +12,7 @@ import subprocess
 import pytest
 
 from oracle.make_fixtures import patch_namelist
+from rslmtoasa_amd._proc import run_with_unlimited_stack
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INPUTS = os.path.join(ROOT, "tests", "golden", "scf", "inputs")
@@ -31,8 +32,7 @@ def run(mode, case, patch, where):
     shutil.copytree(os.path.join(INPUTS, case), work)
     inp = work / "input.nml"
     inp.write_text(patch_namelist(inp.read_text(), patch))
-    env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
-    r = subprocess.run(["bash", "-c", "ulimit -s unlimited; exec %s %s" % (EXE, mode)], cwd=work, env=env, capture_output=True, text=True, timeout=900)
+    r = run_with_unlimited_stack([EXE, mode], cwd=work, env={"OMP_NUM_THREADS": "4"}, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     return work, r.stdout
 
