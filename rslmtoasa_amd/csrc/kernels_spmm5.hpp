@@ -471,19 +471,20 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = LDSA ? (int)((spin_by_xcd ? blockIdx.x : (blockIdx.x >> 3)) & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
-    constexpr int WGG = LDSA ? 2 * S5_WG_GROUPS : S5_WG_GROUPS;       // groups per workgroup
+    const int WGG = LDSA ? (int)(blockDim.x >> 6) : S5_WG_GROUPS;     // groups per workgroup (LDSA: one per wave; 8 waves, or 4 when the launch leaves half of the CU to other kernels)
     if constexpr (LDSA) {
         const s5_d2* __restrict__ src = reinterpret_cast<const s5_d2*>(frag + ((size_t)lds_tau * 2 + sig) * ntr * S5_TRIPLE);
         s5_d2* dst = reinterpret_cast<s5_d2*>(s5_lds);
         // all loads of a thread in flight at once (a rolled loop paid one memory latency per iteration: the copy then cost more than
         // the LDS reads save, because a workgroup lives for one round of groups only)
         const int n = ntr * (S5_TRIPLE / 2);
-        constexpr int PER = (int)(160 * 1024 / 16 / (S5_WG_GROUPS * 128));     // 20: the LDS limit over the workgroup's threads
+        constexpr int PER = (int)(160 * 1024 / 16 / (S5_WG_GROUPS * 64));      // 40: the LDS limit over the threads of a 4-wave workgroup
+        const int nthr = (int)blockDim.x;
         s5_d2 v[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * (S5_WG_GROUPS * 128); if (e < n) v[i] = src[e]; }
+        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * nthr; if (e < n) v[i] = src[e]; }
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * (S5_WG_GROUPS * 128); if (e < n) dst[e] = v[i]; }
+        for (int i = 0; i < PER; ++i) { const int e = threadIdx.x + i * nthr; if (e < n) dst[e] = v[i]; }
         __syncthreads();
     }
     const int l15 = lane & 15, l4 = lane >> 4;

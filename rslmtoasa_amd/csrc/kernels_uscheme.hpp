@@ -218,6 +218,124 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
 }
 
+// ---- two waves per SIMD ------------------------------------------------------------------------------------------------
+// The kernel above is bound by neither pipe: 11.6 GB per launch at 4.6 TB/s, matrix pipe 52 % busy, 73 % of the wave cycles in waits
+// (profiles/r02t_c2_sq_pmc.txt) -- per 16-row tile the matrix work is 4848 cycles for 18.4 KB of traffic, i.e. the kernel needs
+// 9.3 TB/s to keep the pipe full: it is HBM-bound, and ONE 512-register wave per SIMD has nothing to cover its own waits with.
+// Here the three coefficient tables (81 doubles per lane = 162 registers) live in LDS instead (41 KB per workgroup, one ds_read_b64
+// per MFMA: 23 B/clk per CU of the LDS's 128) and a wave fits 256 registers: two workgroups per CU, two waves per SIMD, each with the
+// operands of the next row tile in flight.
+template <int F>
+__device__ __forceinline__ void u3_mac_lds(double4_t& ca, double4_t& cb, double& cr, const U3Operands& o, const double* __restrict__ T /*LDS: [27][64] + lane*/, bool odd) {
+#define U3L_STEP(Q)                                                                             \
+    {                                                                                           \
+        const double a = u3_k<Q>(o, odd);                                                          \
+        ca = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(3 * (Q) + 0) * 64], ca, 0, 0, 0);       \
+        cb = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[(3 * (Q) + 1) * 64], cb, 0, 0, 0);       \
+        cr = __builtin_amdgcn_mfma_f64_4x4x4f64(a, T[(3 * (Q) + 2) * 64], cr, 0, 0, 0);         \
+    }
+    U3L_STEP(0) U3L_STEP(1) U3L_STEP(2) U3L_STEP(3) U3L_STEP(4) U3L_STEP(5) U3L_STEP(6) U3L_STEP(7) U3L_STEP(8)
+#undef U3L_STEP
+}
+
+__global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_orth3w(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
+                                                                 const double* __restrict__ ucur, double* uprev,
+                                                                 const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/) {
+    __shared__ double lds[MF_WAVES * 1296];          // = 3 * 27 * 64: the three tables during the pass, the waves' Gram images at its end
+    const int chain = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = CV.count_of(chain, level) / GROUP;
+    const int* order = CV.order_of(chain, level);
+    const size_t vo = (size_t)chain * CV.vstride;
+    const double* tv = tvec + vo;
+    const double* uc = ucur + vo;
+    double* up = uprev + vo;
+    const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
+    {
+        const double* f = tabs + (size_t)chain * 3 * 27 * 64;
+        for (int e = threadIdx.x; e < 3 * 27 * 64; e += MF_WAVES * 64) lds[e] = f[e];
+        __syncthreads();
+    }
+    const double* T1 = lds + lane;
+    const double* T2 = lds + 27 * 64 + lane;
+    const double* T3 = lds + 54 * 64 + lane;
+    GramAcc Gm;
+    Gm.zero();
+    const int nbx = active_workgroups(ngroups);
+    GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx);
+    const int ntile = (w.g < w.end) ? ((w.end - w.g + w.step - 1) / w.step) * 9 : 0;
+    struct TileAtoms { int s0, a_lo, a_hi; };
+    auto tile_atoms = [&](int it) {
+        it = min(it, ntile - 1);
+        const int* __restrict__ grp = order + (size_t)(w.g + (it / 9) * w.step) * GROUP;
+        TileAtoms t;
+        t.s0 = (16 * (it % 9)) / 18;
+        t.a_lo = grp[t.s0];
+        t.a_hi = grp[min(t.s0 + 1, GROUP - 1)];
+        return t;
+    };
+    auto tile_row = [&](const TileAtoms& t, int rho) {
+        const bool hi = rho >= 18 * (t.s0 + 1);
+        const int a = hi ? t.a_hi : t.a_lo;
+        RowRef R;
+        R.valid = a >= 0;
+        R.off = (unsigned)BLD * (unsigned)(R.valid ? a : zero_block) + 36u * (unsigned)(rho - 18 * (t.s0 + (hi ? 1 : 0)));
+        return R;
+    };
+    auto load_tile = [&](int it, U3Operands& a, U3Operands& c, U3Operands& p) {
+        const TileAtoms t = tile_atoms(it);
+        const RowRef ra = tile_row(t, 16 * (min(it, ntile - 1) % 9) + l15);
+        u3_load(a, tv, ra.off, l4);
+        u3_load(c, uc, ra.off, l4);
+        u3_load(p, up, ra.off, l4);
+    };
+    auto compute_tile = [&](int it, const U3Operands& ot, const U3Operands& oc, const U3Operands& op) {
+        const TileAtoms ta = tile_atoms(it);
+        const int mt = it % 9;
+        double4_t ca = (double4_t){0, 0, 0, 0}, cb = (double4_t){0, 0, 0, 0};
+        double cr = 0.0;
+        u3_mac_lds<0>(ca, cb, cr, ot, T1, l4 & 1);
+        u3_mac_lds<1>(ca, cb, cr, op, T2, l4 & 1);
+        u3_mac_lds<2>(ca, cb, cr, oc, T3, l4 & 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const RowRef rs = tile_row(ta, 16 * mt + l4 + 4 * j);
+            if (rs.valid) { up[rs.off + l15] = ca[j]; up[rs.off + 16 + l15] = cb[j]; }
+        }
+        const RowRef rr = tile_row(ta, 16 * mt + 4 * lg + l4);
+        if (rr.valid) up[rr.off + 32 + l3] = cr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double fr = __shfl(cr, l3 + 4 * j + 16 * l4, 64);      // Y[row 4 j + l4][32 + l3]
+            const double f0 = ca[j], f1 = cb[j];
+            Gm.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, Gm.t00, 0, 0, 0);
+            Gm.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, Gm.t01, 0, 0, 0);
+            Gm.t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, Gm.t11, 0, 0, 0);
+            Gm.tr0 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f0, Gm.tr0, 0, 0, 0);
+            Gm.tr1 = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, f1, Gm.tr1, 0, 0, 0);
+            Gm.trr = __builtin_amdgcn_mfma_f64_4x4x4f64(fr, fr, Gm.trr, 0, 0, 0);
+        }
+    };
+    U3Operands at, ac, ap, bt, bc, bp;
+    if (ntile > 0) load_tile(0, at, ac, ap);
+#pragma unroll 1
+    for (int it = 0; it < ntile; it += 2) {
+        load_tile(it + 1, bt, bc, bp);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tile(it, at, ac, ap);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < ntile) {
+            load_tile(it + 2, at, ac, ap);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(it + 1, bt, bc, bp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                   // every wave is done with the tables: the buffer becomes the Gram staging area
+    gram_block_out(Gm, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, true);
+}
+
 // G = sum u_n^H t'  ->  A_n = Binv_n G Binv_n (the coefficient, recursion.f90:1642), T3 = -Binv_n A_n
 __global__ __launch_bounds__(1024) void k_reduce_a_u(const double* __restrict__ partial, int nblk, double2* a_out, size_t astride,
                                                     const double2* __restrict__ Bmats /*[chain][2][324]: B_n, Binv_n*/, double* tabs, int ci) {

@@ -100,6 +100,14 @@ struct rsrec_handle {
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
+    long opt_s5_waves = 8;
+    long opt_orth3 = 1;          // k_mfma_orth3: 1 one 512-register wave per SIMD (tables in registers), 2 two waves per SIMD (tables in LDS)
+    long opt_graph = 1;          // level loop of small batches as one HIP graph: 0 never, 1 calls of up to 8 chains, 2 every single-batch call
+    // The captured level loop of the last small-batch block-Lanczos call (every SCF iteration repeats it with the same lattice, seeds,
+    // depth and buffers; the operator's VALUES are read through device pointers and may change).  key = everything the nodes hold by value.
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uintptr_t> graph_key;
+    bool capturing = false;      // between hipStreamBeginCapture and hipStreamEndCapture: no timing events, no allocation
     // timing of last call
     double t_total_ms = 0, t_hop_ms = 0, t_rest_ms = 0, t_host_ms = 0;
     double n_hop_launch = 0, n_atom_steps = 0, n_block_mult = 0, n_hop_mfma_flop = 0;   // mfma_flop: matrix flops EXECUTED by the timed k_spmm5 launches
@@ -153,7 +161,7 @@ int fail(rsrec_t* h, int code, const char* fmt, ...) {
 
 hipEvent_t next_event(rsrec_t* h) {
     static const bool off = getenv("RSREC_NO_EVENTS") != nullptr;      // diagnostics only
-    if (off) return nullptr;
+    if (off || h->capturing) return nullptr;
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -339,6 +347,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (hipEvent_t e : h->ev_green) if (e) (void)hipEventDestroy(e);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_orth) (void)hipEventDestroy(h->ev_orth);
     if (h->ev_bred) (void)hipEventDestroy(h->ev_bred);
@@ -367,6 +376,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
     else if (!strcmp(key, "cheb_fused")) h->opt_cheb_fused = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
+    else if (!strcmp(key, "graph")) h->opt_graph = value;
+    else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
+    else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -843,6 +855,20 @@ const double* presum(rsrec_t* h, const double* partial, int nb, int& nblk, int w
 // atoms (a bulk crystal of one type: every group runs the same stream) whose stream of one spin fits the CU's LDS; per-chain stream
 // heads (local-axis runs) keep the global-load variant.
 constexpr size_t S5_LDS_LIMIT = 160 * 1024;
+// LDS a k_spmm5 workgroup may ask for: what the device grants on request (160 KB on MI355X); asked for once per handle, i.e. per device --
+// the attribute is a property of the (function, device) pair, a second handle on another GPU of the process needs its own opt-in
+void s5_prepare(rsrec_t* h) {
+    if (h->s5_lds_limit != (size_t)-1) return;
+    int optin = 0;
+    h->s5_lds_limit = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, h->device) == hipSuccess && optin > 64 * 1024) {
+        const int ask = (int)std::min<size_t>((size_t)optin, S5_LDS_LIMIT);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
+            h->s5_lds_limit = (size_t)ask;
+    }
+    (void)hipGetLastError();
+}
 template <bool TWO>
 void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
                const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0, S5Epilogue epi = S5Epilogue()) {
@@ -850,19 +876,7 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
     const int one = op.single_class(set);
     // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
     const bool want = h->opt_s5_lds >= 1;
-    // LDS a workgroup may ask for: what the device grants on request (160 KB on MI355X); asked for once per handle, i.e. per device --
-    // the attribute is a property of the (function, device) pair, a second handle on another GPU of the process needs its own opt-in
-    if (h->s5_lds_limit == (size_t)-1) {
-        int optin = 0;
-        h->s5_lds_limit = 0;
-        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, h->device) == hipSuccess && optin > 64 * 1024) {
-            const int ask = (int)std::min<size_t>((size_t)optin, S5_LDS_LIMIT);
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
-                h->s5_lds_limit = (size_t)ask;
-        }
-        (void)hipGetLastError();
-    }
+    s5_prepare(h);
     const size_t lds_limit = h->s5_lds_limit;
     if (want && one >= 0 && !extra && lds_bytes <= lds_limit) {
         const int spin_by_xcd = op.spin_mixing ? 0 : 1;
@@ -872,13 +886,17 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
         const unsigned ncu = (unsigned)std::max(16, h->n_cu / 16 * 16);     // whole rows of 8 / 16 workgroups (the kernel's XCD mapping)
         if ((h->opt_s5_queue == 1 && grid.x >= ncu) || h->opt_s5_queue >= 2) {
             // persistent form: one workgroup per CU for the whole launch, groups from per-(chain, XCD[, spin]) counters
-            if (h->d_s5queue.reserve((size_t)SD.nchains * 16 * sizeof(int)) == hipSuccess &&
+            if ((!h->capturing || h->d_s5queue.bytes >= (size_t)SD.nchains * 16 * sizeof(int)) &&     // (no allocation inside a stream capture)
+                h->d_s5queue.reserve((size_t)SD.nchains * 16 * sizeof(int)) == hipSuccess &&
                 hipMemsetAsync(h->d_s5queue.p, 0, (size_t)SD.nchains * 16 * sizeof(int), h->stream) == hipSuccess) {
                 queue = h->d_s5queue.as<int>();
                 g2 = dim3(ncu, 1);
             }
         }
-        k_spmm5<TWO, true><<<g2, S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
+        // s5_waves = 4 (persistent form only): half-size workgroups, one wave per SIMD -- the other half of every CU's registers stays free
+        // for the kernels of another stream (the HBM-bound post-hop passes of the other half batch)
+        const unsigned thr = (queue && h->opt_s5_waves == 4) ? S5_WG_GROUPS * 64 : S5_WG_GROUPS * 128;
+        k_spmm5<TWO, true><<<g2, thr, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
         k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0, nullptr, 1, epi);
     if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)
@@ -889,11 +907,15 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
 bool spmm4_usable(const rsrec_t* h) { return h->s4_built_split && (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32); }
 
 // small-launch SpMM on LayoutRM vectors: out = sum_slots H_slot in_nbr, four waves share one group of atoms (k_spmm4<4>)
-int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
+int s4_prepare(rsrec_t* h) {
     if (!h->s4_attr) {
         HIPCK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm4<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4_LDS_BYTES));
         h->s4_attr = true;
     }
+    return RSREC_OK;
+}
+int launch_spmm(rsrec_t* h, const SpmmDims& SD, const ChainView& CV, const DevProblem& P, int set, const double* in, double* out, dim3 grid_mf) {
+    { const int rc = s4_prepare(h); if (rc) return rc; }
     // one group per workgroup at a time: 4x as many workgroups keep the same number of groups in flight per launch
     dim3 g4(std::min<unsigned>(grid_mf.x * 4, 1024), grid_mf.y);
     k_spmm4<4><<<g4, MF_WAVES * 64, S4_LDS_BYTES, h->stream>>>(SD, CV.order, CV.cum, P.nbr, P.iz, h->s4_op.frag_set(set), h->s4_op.meta_set(set), in, out);
@@ -1016,95 +1038,138 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
 
         ChainView CV;
         CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
-        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
-        HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
-        HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
-        if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
-        psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (swapped every level)
-        if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
-        else k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
-        k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
-        if (MFMA) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags, ci);
-        const dim3 grid(nblk, nb);
-        const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
-        // u-scheme: H u_{n+1} does not need B_{n+1}, so the reduction of sum u_{n+1}^H u_{n+1} and its 18x18 eigen-solve (one
-        // workgroup per chain, 80 us) leave the critical path: they run on the side stream while the main stream already applies H.
-        // The main stream waits for them before k_reduce_a_u of the next level (first consumer of Binv_{n+1}).
-        const bool side = h->opt_side && h->side_stream;
-        double* gp_b = side ? gpartial_b : gpartial;
-        bool b_pending = false;
-        auto wait_b_level = [&]() -> int {
-            if (b_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); b_pending = false; }
-            return RSREC_OK;
-        };
-        auto reduce_b_level = [&](int nwg, int ll) -> int {
-            hipStream_t st = h->stream;
-            if (side) {
-                HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
-                HIPCK(h, hipStreamWaitEvent(h->side_stream, h->ev_orth, 0));
-                st = h->side_stream;
-            }
-            int n2 = nwg;
-            const double* p2 = presum(h, gp_b, nb, n2, 1296, st, side ? 1 : 0);
-            k_reduce_b_u<<<nb, 1024, 0, st>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags, h->d_status.as<int>(), ci);
-            if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); b_pending = true; }
-            return RSREC_OK;
-        };
-        for (int ll = 0; ll < nsteps; ++ll) {
-            const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
-            const double* tvec = nullptr;                      // H psi when it is held in a vector of its own
-            hipEvent_t e0 = next_event(h);
-            hipEvent_t e1 = nullptr;
-            ApplyArgs G{};
-            G.partial = partial;
-            if (MFMA) {
-                // matrix-core kernel set, un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
-                SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * ll + 1 : lv_final, velems, CV.obase, nb};
-                if (!hoh) {
-                    if (ci && rot) launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi, psi, la_extra, ntau);
-                    else if (ci) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi);
-                    else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
-                } else {
-                    // H = h - (h o) h + e_nu + l.s in two passes of k_spmm5: h psi, then the rest with psi as second input (extra on-site slot)
-                    double* hps = pmn;                   // (the pmn buffer is free in the u-scheme)
-                    launch_s5<false>(h, s5_grid(h, grid_mf, 2 * ll + 1), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hps);
-                    SD.level = lv_final;
-                    launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 1, hps, hpsi, psi, la_extra, ntau);
+        // Everything from here to the coefficients' download is stream work only (kernels, memsets, cross-stream events): for small
+        // batches it is captured ONCE as a HIP graph and replayed by every later call with the same lattice, seeds, depth and buffers
+        // (each SCF iteration of the reference: recur_b on the same <= 4 sites) -- 49 levels x 6-8 dependent launches otherwise cost
+        // more host time than device time (13 ms for one site of the 22^3 cell, two thirds of it launch latency).
+        auto enqueue_levels = [&]() -> int {
+            for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+            HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
+            HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
+            if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
+            psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (swapped every level)
+            if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+            else k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
+            k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
+            if (MFMA) k_uscheme_init<<<nb, 256, 0, h->stream>>>(h->d_bmats.as<double2>(), bfrags, ci);
+            const dim3 grid(nblk, nb);
+            const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, B), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+            // u-scheme: H u_{n+1} does not need B_{n+1}, so the reduction of sum u_{n+1}^H u_{n+1} and its 18x18 eigen-solve (one
+            // workgroup per chain, 80 us) leave the critical path: they run on the side stream while the main stream already applies H.
+            // The main stream waits for them before k_reduce_a_u of the next level (first consumer of Binv_{n+1}).
+            const bool side = h->opt_side && h->side_stream;
+            double* gp_b = side ? gpartial_b : gpartial;
+            bool b_pending = false;
+            auto wait_b_level = [&]() -> int {
+                if (b_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); b_pending = false; }
+                return RSREC_OK;
+            };
+            auto reduce_b_level = [&](int nwg, int ll) -> int {
+                hipStream_t st = h->stream;
+                if (side) {
+                    HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
+                    HIPCK(h, hipStreamWaitEvent(h->side_stream, h->ev_orth, 0));
+                    st = h->side_stream;
                 }
-                e1 = next_event(h);
-                const dim3 gl = level_grid(h, grid_mf, lv_final);
-                k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
-                { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
-                  rc = wait_b_level(); if (rc) return rc;
-                  k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
-                k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                rc = reduce_b_level(gl.x, ll); if (rc) return rc;
-                std::swap(psi, t2);
-                hop_ev.emplace_back(e0, e1);
+                int n2 = nwg;
+                const double* p2 = presum(h, gp_b, nb, n2, 1296, st, side ? 1 : 0);
+                k_reduce_b_u<<<nb, 1024, 0, st>>>(p2, n2, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), bfrags, h->d_status.as<int>(), ci);
+                if (side) { HIPCK(h, hipEventRecord(h->ev_bred, h->side_stream)); b_pending = true; }
+                return RSREC_OK;
+            };
+            for (int ll = 0; ll < nsteps; ++ll) {
+                const int lv_final = hoh ? 2 * ll + 2 : ll + 1;
+                const double* tvec = nullptr;                      // H psi when it is held in a vector of its own
+                hipEvent_t e0 = next_event(h);
+                hipEvent_t e1 = nullptr;
+                ApplyArgs G{};
+                G.partial = partial;
+                if (MFMA) {
+                    // matrix-core kernel set, un-normalised vectors (kernels_uscheme.hpp): psi = u_n, t2 = u_{n-1}; u_{n+1} overwrites u_{n-1}
+                    SpmmDims SD{kk, P.nslots, P.nmax, nlev, 1, ostride, hoh ? 2 * ll + 1 : lv_final, velems, CV.obase, nb};
+                    if (!hoh) {
+                        if (ci && rot) launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi, psi, la_extra, ntau);
+                        else if (ci) launch_s5<false>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hpsi);
+                        else { rc = launch_spmm(h, SD, CV, P, 0, psi, hpsi, grid_mf); if (rc) return rc; }
+                    } else {
+                        // H = h - (h o) h + e_nu + l.s in two passes of k_spmm5: h psi, then the rest with psi as second input (extra on-site slot)
+                        double* hps = pmn;                   // (the pmn buffer is free in the u-scheme)
+                        launch_s5<false>(h, s5_grid(h, grid_mf, 2 * ll + 1), SD, CV.order, CV.cum, P.iz, OP, 0, psi, hps);
+                        SD.level = lv_final;
+                        launch_s5<true>(h, s5_grid(h, grid_mf, lv_final), SD, CV.order, CV.cum, P.iz, OP, 1, hps, hpsi, psi, la_extra, ntau);
+                    }
+                    e1 = next_event(h);
+                    const dim3 gl = level_grid(h, grid_mf, lv_final);
+                    k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                    { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
+                      rc = wait_b_level(); if (rc) return rc;
+                      k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
+                    if (h->opt_orth3 == 2) k_mfma_orth3w<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                else k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                    rc = reduce_b_level(gl.x, ll); if (rc) return rc;
+                    std::swap(psi, t2);
+                    hop_ev.emplace_back(e0, e1);
+                    h->n_hop_launch += hoh ? 2 : 1;
+                    continue;
+                }
+                // FP64 VALU kernel set: the reference's literal order on the reference's layout
+                if (!hoh) {
+                    G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                    k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    e1 = next_event(h);
+                } else {
+                    G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
+                    k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    G.in = hpsi; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
+                    k_apply<AM_HOH_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
+                    e1 = next_event(h);
+                }
+                hop_ev.emplace_back(e0, e1);                       // [e0,e1] brackets exactly the H|psi> kernel(s) of this step
                 h->n_hop_launch += hoh ? 2 : 1;
-                continue;
+                k_reduce_a<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride);
+                k_orth<L><<<grid, NTHREADS, orth_lds, h->stream>>>(CV, lv_final, psi, pmn, tvec, dA + (size_t)ll * BLK, cstride, partial);
+                k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(partial, nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
+                k_update<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
             }
-            // FP64 VALU kernel set: the reference's literal order on the reference's layout
-            if (!hoh) {
-                G.in = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                k_apply<AM_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                e1 = next_event(h);
-            } else {
-                G.in = psi; G.out = hpsi; G.level = 2 * ll + 1;
-                k_apply<AM_STORE, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                G.in = hpsi; G.v1 = hpsi; G.cur = psi; G.v0 = psi; G.out = pmn; G.level = lv_final;
-                k_apply<AM_HOH_LANCZOS, L><<<grid, NTHREADS, 0, h->stream>>>(P, CV, G);
-                e1 = next_event(h);
+            HIPCK(h, hipGetLastError());
+            rc = wait_b_level(); if (rc) return rc;
+            return RSREC_OK;
+        };
+        const bool use_graph = MFMA && nchains <= B && ((h->opt_graph == 1 && nchains <= 8) || h->opt_graph >= 2) && getenv("RSREC_NO_GRAPH") == nullptr;
+        if (!use_graph) { rc = enqueue_levels(); if (rc) return rc; }
+        else {
+            if (ci) HIPCK(h, h->d_s5queue.reserve((size_t)nb * 16 * sizeof(int)));
+            // what the nodes hold BY VALUE: every pointer and dimension a kernel argument is made of
+            std::vector<uintptr_t> key = {(uintptr_t)1 /*block Lanczos*/, (uintptr_t)nb, (uintptr_t)lld, (uintptr_t)nseed, (uintptr_t)hoh, (uintptr_t)ci, (uintptr_t)(rot != nullptr), (uintptr_t)kk,
+                                          (uintptr_t)h->cur_order, (uintptr_t)h->cur_cum, (uintptr_t)ostride, (uintptr_t)OP.d_frag, (uintptr_t)OP.d_meta, (uintptr_t)OP.ntr,
+                                          (uintptr_t)h->s4_op.frag_set(0), (uintptr_t)h->s4_op.meta_set(0), (uintptr_t)h->d_nbr.p, (uintptr_t)h->d_nbr5.p, (uintptr_t)h->d_iz.p,
+                                          (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
+                                          (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
+                                          (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue,
+                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing};
+            for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
+            if (!h->graph_exec || key != h->graph_key) {
+                if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+                h->graph_key.clear();
+                s5_prepare(h);
+                rc = s4_prepare(h); if (rc) return rc;
+                HIPCK(h, hipStreamSynchronize(h->stream));
+                HIPCK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+                h->capturing = true;
+                rc = enqueue_levels();
+                h->capturing = false;
+                hipGraph_t graph = nullptr;
+                const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                if (ec != hipSuccess || !graph) return fail(h, RSREC_ERR_DEVICE, "hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+                const hipError_t ei = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ei != hipSuccess) { h->graph_exec = nullptr; return fail(h, RSREC_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+                h->graph_key = key;
             }
-            hop_ev.emplace_back(e0, e1);                       // [e0,e1] brackets exactly the H|psi> kernel(s) of this step
-            h->n_hop_launch += hoh ? 2 : 1;
-            k_reduce_a<<<nb, 1024, 0, h->stream>>>(partial, nblk, dA + (size_t)ll * BLK, cstride);
-            k_orth<L><<<grid, NTHREADS, orth_lds, h->stream>>>(CV, lv_final, psi, pmn, tvec, dA + (size_t)ll * BLK, cstride, partial);
-            k_reduce_b_eig<<<nb, 1024, 0, h->stream>>>(partial, nblk, dB + (size_t)(ll + 1) * BLK, cstride, h->d_bmats.as<double2>(), h->d_status.as<int>());
-            k_update<L><<<grid, NTHREADS, 0, h->stream>>>(CV, lv_final, psi, pmn, h->d_bmats.as<double2>());
+            HIPCK(h, hipGraphLaunch(h->graph_exec, h->stream));
+            h->n_hop_launch += (double)nsteps * (hoh ? 2 : 1);
         }
-        HIPCK(h, hipGetLastError());
-        rc = wait_b_level(); if (rc) return rc;
         XFER(xfer_d2h(h, a_b + (size_t)c0 * cstride * 2, dA, (size_t)nb * cstride * sizeof(double2)));
         XFER(xfer_d2h(h, b2_b + (size_t)c0 * cstride * 2, dB, (size_t)nb * cstride * sizeof(double2)));
         HIPCK(h, hipStreamSynchronize(h->stream));

@@ -1,0 +1,67 @@
+"""The small-batch level loop as a HIP graph (option `graph`): every SCF call of the reference runs recur_b on <= 4 sites, 19-49
+levels x 6-8 dependent launches each (crecal_b, recursion.f90:1873-1973).  The captured graph must be invisible in the results:
+bitwise equal to the launch-per-kernel path on the first call (capture + launch), on replays, and after the operator's VALUES change
+(the nodes hold pointers, not blocks); a changed lattice, depth or seed list must re-capture."""
+import numpy as np
+import pytest
+
+from helpers import RTOL, load_golden_with_inputs, objects_from, problem_dict, rel_err, supercell_problem
+from rslmtoasa_amd.recursion import Recursion
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hoh", [False, True])
+@pytest.mark.parametrize("spmm5", [1, 2])
+def test_graph_replay_is_bitwise_the_launch_path(hoh, spmm5):
+    p = supercell_problem((6, 6, 6), hoh=hoh)
+    sites = np.array([1, 100, 216], dtype=np.int32)
+    rec = Recursion(*objects_from(p, sites, 14), device=0)
+    rec.set_option("spmm5", spmm5)
+    rec.set_option("graph", 0)
+    rec.recur_b()
+    a0, b0 = rec.a_b.copy(), rec.b2_b.copy()
+    rec.set_option("graph", 1)
+    for _ in range(3):                      # capture + launch, then two replays
+        rec.a_b[:] = 0
+        rec.b2_b[:] = 0
+        rec.recur_b()
+        assert np.array_equal(rec.a_b, a0) and np.array_equal(rec.b2_b, b0)
+    # new operator values, same pointers: the replayed graph must see them
+    rec.hamiltonian.ee = rec.hamiltonian.ee * 1.25
+    rec.update_hamiltonian()
+    rec.recur_b()
+    a1 = rec.a_b.copy()
+    assert np.abs(a1 - a0).max() > 1e-3
+    rec.set_option("graph", 0)
+    rec.recur_b()
+    assert np.array_equal(rec.a_b, a1)
+    rec.close()
+
+
+def test_graph_recaptures_when_depth_or_seeds_change(oracle_lib):
+    p = supercell_problem((4, 4, 8))
+    o = oracle_lib.Oracle(p)
+    rec = Recursion(*objects_from(p, np.array([1, 77], dtype=np.int32), 10), device=0)
+    rec.recur_b()
+    rec.recur_b()
+    a_o, b_o = o.block_lanczos(np.array([1, 77], dtype=np.int32), 10)
+    assert rel_err(rec.a_b, a_o) < RTOL and rel_err(rec.b2_b, b_o) < RTOL
+    rec.close()
+    rec = Recursion(*objects_from(p, np.array([5, 9, 33], dtype=np.int32), 7), device=0)
+    rec.recur_b()
+    rec.recur_b()
+    a_o, b_o = o.block_lanczos(np.array([5, 9, 33], dtype=np.int32), 7)
+    assert rel_err(rec.a_b, a_o) < RTOL and rel_err(rec.b2_b, b_o) < RTOL
+    rec.close()
+
+
+@pytest.mark.parametrize("name", ["B2FeCo_block_hoh", "fccCu001_block_hoh"])
+def test_graph_on_the_reference_cases(name):
+    """The reference's own impurity / surface SCF cases (2 sites, per-atom hall blocks resp. 3 types): graph path vs golden coefficients."""
+    g = load_golden_with_inputs(name)
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], int(g["lld"]), nsp=int(g["nsp"])), device=0)
+    for _ in range(2):
+        rec.recur_b()
+        assert rel_err(rec.a_b, g["a_b"]) < RTOL and rel_err(rec.b2_b, g["b2_b"]) < RTOL
+    rec.close()
