@@ -16,6 +16,12 @@ Other workloads of BASELINE.json (same metric, named in config.workload):
   --recur chebyshev       configs[3] shape: Chebyshev moments (chebyshev_recur, recursion.f90:3057)
   --spin-mixing           the same stencil in a spin frame tilted by 60 degrees: every hopping block has spin-flip entries
                           (non-collinear operator; nothing is skipped as a structural zero)
+  --workload fccCu001     configs[3]: the reference's surface case (tests/scf/cases/surface/fccCu001: fcc Cu(001) slab cluster, 9 318 atoms,
+                          THREE atom types, 19 neighbour slots), Chebyshev recursion LL=50, 64 sites; lattice tables and blocks from the
+                          committed fixture tests/golden/fccCu001_cheb.npz (the reference holds no Fe(001) case)
+  --workload B2FeCo       configs[4]: the reference's impurity case (tests/scf/cases/impurity/B2FeCo: 4 152 atoms, nmax = 15 atoms with
+                          per-atom `hall` blocks + 3 bulk types), block Lanczos with hoh, LL=50; sites = the 15 impurity-region atoms
+                          (per-site LDOS of all inequivalent atoms) + 49 host atoms; fixture tests/golden/B2FeCo_block_hoh.npz
 
 Sites are independent: with N GPUs every rank owns S sites (weak scaling), no collective inside the loop.
 
@@ -50,7 +56,8 @@ def parse_args():
     ap.add_argument("--sites", type=int, default=64, help="recursion sites per GPU per step")
     ap.add_argument("--cells", type=int, default=22, help="n for the n^3 periodic bcc supercell")
     ap.add_argument("--lld", type=int, default=50)
-    ap.add_argument("--recur", choices=("block", "chebyshev"), default="block")
+    ap.add_argument("--recur", choices=("block", "chebyshev"), default=None, help="default: block (chebyshev for --workload fccCu001)")
+    ap.add_argument("--workload", choices=("bcc", "fccCu001", "B2FeCo"), default="bcc", help="bcc: synthetic periodic bcc Fe supercell (--cells); others: lattices of the reference's own cases")
     ap.add_argument("--hoh", action="store_true")
     ap.add_argument("--spin-mixing", action="store_true", help="stencil rotated into a tilted spin frame: spin-flip entries in every block")
     ap.add_argument("--kernels", type=int, default=0)
@@ -61,7 +68,12 @@ def parse_args():
     ap.add_argument("--no-green", action="store_true", help="skip the (untimed, separately reported) LDOS stage")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--master-port", type=int, default=0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.recur is None:
+        args.recur = "chebyshev" if args.workload == "fccCu001" else "block"
+    if args.workload == "B2FeCo":
+        args.hoh = True
+    return args
 
 
 def launch_ranks(args):
@@ -104,6 +116,72 @@ def tilt_spin_frame(st, theta):
     return out
 
 
+def algorithmic_work(nn, seed, napply, hoh):
+    """Block multiplies and post-hop atom-steps of ONE chain from `seed` (1-based) in the reference's count (hop_b :1576-1625: one zgemm
+    per (atom, slot) whose source atom is inside the region; hop_b_hoh: two passes + the two on-site products): any lattice table."""
+    import numpy as np
+    kk = nn.shape[0]
+    nb = int(nn[:, 0].max())
+    nbr = nn[:, 1:nb]
+    fan = 1 + np.bincount(nbr[nbr > 0].ravel(), minlength=kk + 1)[1:]          # on-site + every atom that lists n as a neighbour
+    active = np.zeros(kk + 1, dtype=bool)
+    active[seed] = True
+    mults = atom_steps = 0.0
+    for _ in range(napply):
+        for p in range(2 if hoh else 1):
+            mults += float(fan[active[1:]].sum()) + (2.0 * float(active[1:].sum()) if (hoh and p == 0) else 0.0)
+            hit = active[nbr].any(axis=1)
+            active[1:] |= hit
+            active[0] = False
+        atom_steps += float(active[1:].sum())
+    return mults, atom_steps
+
+
+def build_workload(args, world):
+    """The recursion problem of a bench run: tables, blocks, the sites of all ranks, and the names the JSON line carries."""
+    import numpy as np
+    from rslmtoasa_amd.lattice import bcc_supercell, spread_sites, supercell_positions
+    nsites_total = args.sites * world
+    W = {"emin": -3.0, "emax": 1.8}       # Chebyshev window of the reference's Chebyshev cases (tests/golden/*_cheb.npz; SURVEY 8, C4)
+    if args.workload == "bcc":
+        st = load_stencil(args.hoh)
+        if args.spin_mixing:
+            st = tilt_spin_frame(st, np.pi / 3)
+        n = args.cells
+        nn = bcc_supercell((n, n, n), st["slot_vec"])
+        kk = nn.shape[0]
+        variant = ("hoh " if args.hoh else "") + ("spin-mixing " if args.spin_mixing else "")
+        W.update(nn=nn, iz=np.ones(kk, np.int32), nmax=0, ntype=1, ee=st["ee"], lsham=st["lsham"], eeo=st.get("eeo"), enim=st.get("enim"), hall=None, hallo=None,
+                 cr=None if args.no_positions else supercell_positions((n, n, n)), irec=spread_sites(kk, nsites_total),
+                 name="bcc Fe %d^3 = %d atoms, nsp=2 18x18 blocks, %s%s LL=%d, %d sites per GPU per step"
+                      % (n, kk, variant, "block Lanczos" if args.recur == "block" else "Chebyshev", args.lld, args.sites),
+                 key="%s%s%s_c%d_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", "_mix" if args.spin_mixing else "", n, args.sites, args.lld),
+                 data="synthetic periodic bcc lattice; physical Fe spd stencil (18x18 complex blocks) dumped from the reference's bulk/bccFe case")
+        return W
+    if args.spin_mixing or args.cells != 22:
+        print("bench.py: --cells / --spin-mixing belong to --workload bcc", file=sys.stderr)
+        sys.exit(2)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_golden_with_inputs
+    if args.workload == "fccCu001":
+        g = load_golden_with_inputs("fccCu001_block_hoh" if args.hoh else "fccCu001_cheb")
+        kk = int(g["kk"])
+        irec = spread_sites(kk, nsites_total)
+        what = "fcc Cu(001) surface cluster of the reference's surface/fccCu001 case: %d atoms, 3 atom types, %d neighbour slots" % (kk, int(g["nn"][:, 0].max()))
+    else:
+        g = load_golden_with_inputs("B2FeCo_block_hoh")
+        kk, nmax = int(g["kk"]), int(g["nmax"])
+        host = nmax + spread_sites(kk - nmax, max(nsites_total - nmax, 1))
+        irec = np.concatenate([np.arange(1, nmax + 1), host])[:nsites_total].astype(np.int32)
+        what = "B2 FeCo impurity cluster of the reference's impurity/B2FeCo case: %d atoms, %d of them with per-atom hall blocks, 3 bulk types" % (kk, nmax)
+    W.update(nn=g["nn"], iz=g["iz"], nmax=int(g.get("nmax", 0)), ntype=g["ee"].shape[3], ee=g["ee"], lsham=g["lsham"], eeo=g.get("eeo") if args.hoh else None,
+             enim=g.get("enim") if args.hoh else None, hall=g.get("hall"), hallo=g.get("hallo") if args.hoh else None, cr=None, irec=irec,
+             name="%s; nsp=2 18x18 blocks, %s%s LL=%d, %d sites per GPU per step" % (what, "hoh " if args.hoh else "", "block Lanczos" if args.recur == "block" else "Chebyshev", args.lld, args.sites),
+             key="%s%s_%s_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", args.workload, args.sites, args.lld),
+             data="lattice tables and Hamiltonian blocks of the reference's own %s case (committed fixture tests/golden/, dumped from the compiled reference)" % args.workload)
+    return W
+
+
 def cpu_quota():
     """CPU bandwidth limit of this container (cgroup v2 cpu.max / v1 cfs quota), in CPUs; None if unlimited/unknown."""
     try:
@@ -119,7 +197,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
+def cpu_baseline(W, lld, threads, recur, hoh):
     """CPU leg on the host cores of this node, bounded sample = a few sites of the same workload (same lattice, LL).
 
     Preferred: the compiled reference itself (oracle/_ref/ref_kernel.x, built in the build container from the
@@ -127,33 +205,31 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
     for this leg, the compiled reference is the stronger baseline and the task statement allows it as kind "reference").
     Fallback: the C restatement in oracle/ ("port")."""
     import numpy as np
-    from rslmtoasa_amd.lattice import active_region_sizes, spread_sites
-    napply = lld - 1 if recur == "block" else lld + 1
-    sizes = [1] + active_region_sizes(nn, 1, (2 if hoh else 1) * napply)
-    nb = int(nn[0, 0])
-    if not hoh:
-        mults = sum(nb * s for s in sizes[:napply])
-        atom_steps = sum(sizes[1:napply + 1])
-    else:   # two applications per level (+2 on-site products), post-hop work on the region after both
-        mults = sum(nb * (sizes[2 * t] + sizes[2 * t + 1]) + 2 * sizes[2 * t] for t in range(napply))
-        atom_steps = sum(sizes[2 * t + 2] for t in range(napply))
-    flop = FLOP_PER_BLOCK_MULT * (mults + POST_FLOP_BLOCKS[recur] * atom_steps)
     from rslmtoasa_amd._proc import run_with_unlimited_stack, under_profiler
+    nn, emin, emax = W["nn"], W["emin"], W["emax"]
+    napply = lld - 1 if recur == "block" else lld + 1
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_kernel.x")
     if under_profiler():
         print("cpu_baseline skipped: running under a profiler (its preload must not reach a child process)", file=sys.stderr)
         return None
     kk = nn.shape[0]
     what = "recur_b" if recur == "block" else "chebyshev_recur"
+    prob = dict(nn=nn, iz=W["iz"], nmax=W["nmax"], ee=W["ee"], lsham=W["lsham"], hoh=int(hoh), nsp=2)
+    for k in ("eeo", "enim", "hall", "hallo"):
+        if W.get(k) is not None:
+            prob[k] = W[k]
+    # bounded sample: sites of the run's own list, ~4 TFLOP = 10-30 s of CPU work on 16 cores
+    work = [algorithmic_work(nn, int(s), napply, hoh) for s in W["irec"][:CPU_SAMPLE_SITES]]
+    flops = [FLOP_PER_BLOCK_MULT * (m + POST_FLOP_BLOCKS[recur] * a) for m, a in work]
+    nsample = 1
+    while nsample < len(flops) and sum(flops[:nsample + 1]) <= 4.0e12:
+        nsample += 1
+    flop = sum(flops[:nsample])
     if os.path.exists(exe):
         try:
             from oracle import fixture_io as fio
             scratch = tempfile.mkdtemp(prefix="rsrec_cpu_")
-            nsample = max(1, min(CPU_SAMPLE_SITES, int(round(4.0e12 / flop))))          # bounded sample: ~4 TFLOP = 10-30 s of CPU work on 16 cores
-            p = dict(nn=nn, iz=np.ones(kk, np.int32), irec=spread_sites(kk, nsample), lld=lld, nsp=2, hoh=int(hoh), kind=0 if recur == "block" else 1,
-                     ee=st["ee"], lsham=st["lsham"], emin=emin, emax=emax)
-            if hoh:
-                p.update(eeo=st["eeo"], enim=st["enim"])
+            p = dict(prob, irec=np.asarray(W["irec"][:nsample], np.int32), lld=lld, kind=0 if recur == "block" else 1, emin=emin, emax=emax)
             fio.write_kernel_in(os.path.join(scratch, "kernel_in.bin"), p)
             r = run_with_unlimited_stack([exe], cwd=scratch, env={"OMP_NUM_THREADS": str(threads)}, timeout=900)   # scrubbed environment, no shell hop
             t = None
@@ -161,26 +237,25 @@ def cpu_baseline(nn, st, lld, threads, recur, hoh, emin, emax):
                 if "recursion wall time" in line:
                     t = float(line.split()[-2])
             if r.returncode == 0 and t:
-                return {"value": nsample * flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
+                return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": threads, "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
                         "kind": "reference", "seconds": t, "sites_per_s": nsample / t,
-                        "sample": "%d sites of the same %d-atom cell, LL=%d (%.1f GFLOP), compiled reference %s via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (nsample, kk, lld, nsample * flop * 1e-9, what)}
+                        "sample": "%d sites of the same %d-atom lattice, LL=%d (%.1f GFLOP), compiled reference %s via oracle/_ref/ref_kernel.x (amdflang -O2 + MKL, OpenMP)" % (nsample, kk, lld, flop * 1e-9, what)}
             print("cpu_baseline(reference) failed rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]), file=sys.stderr)
         except Exception as e:  # noqa
             print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
     from oracle import oracle
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    o = oracle.Oracle(dict(nn=nn, iz=np.ones(kk, np.int32), ee=st["ee"], lsham=st["lsham"], hoh=int(hoh), nsp=2,
-                           **({"eeo": st["eeo"], "enim": st["enim"]} if hoh else {})))
+    o = oracle.Oracle(prob)
     t0 = time.time()
     if recur == "block":
-        o.block_lanczos(np.array([1], np.int32), lld)
+        o.block_lanczos(np.asarray(W["irec"][:1], np.int32), lld)
     else:
         from rslmtoasa_amd.recursion import chebyshev_scaling
-        o.chebyshev(np.array([1], np.int32), lld, *chebyshev_scaling(emin, emax))
+        o.chebyshev(np.asarray(W["irec"][:1], np.int32), lld, *chebyshev_scaling(emin, emax))
     t = time.time() - t0
-    return {"value": flop / t * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
+    return {"value": flops[0] / t * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(),
             "kind": "port", "seconds": t, "sites_per_s": 1.0 / t,
-            "sample": "1 site of the same %d-atom cell, LL=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (kk, lld, flop * 1e-9)}
+            "sample": "1 site of the same %d-atom lattice, LL=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (kk, lld, flops[0] * 1e-9)}
 
 
 def ldos_stage(rec, gz, ene, nloc, step_s):
@@ -255,19 +330,17 @@ def main():
         assert dist.get_world_size() == args.gpus
         backend = dist.get_backend()
 
-    st = load_stencil(args.hoh)
-    if args.spin_mixing:
-        st = tilt_spin_frame(st, np.pi / 3)
-    n = args.cells
-    nn = bcc_supercell((n, n, n), st["slot_vec"])
+    W = build_workload(args, world)
+    nn = W["nn"]
     kk = nn.shape[0]
     nsites_total = args.sites * world
-    irec = spread_sites(kk, nsites_total)
-    emin, emax = -3.0, 1.8          # Chebyshev window of the reference's Chebyshev cases (tests/golden/*_cheb.npz)
-    lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=irec, nmax=0, ntype=1, cr=None if args.no_positions else supercell_positions((n, n, n)))
-    ham = Hamiltonian(ee=st["ee"], lsham=st["lsham"], eeo=st.get("eeo"), enim=st.get("enim"), hoh=args.hoh)
+    if len(W["irec"]) < nsites_total:
+        print("bench.py: %d sites asked for, the lattice has %d" % (nsites_total, len(W["irec"])), file=sys.stderr)
+        sys.exit(2)
+    lat = Lattice(nn=nn, iz=W["iz"], irec=W["irec"], nmax=W["nmax"], ntype=W["ntype"], cr=W["cr"])
+    ham = Hamiltonian(ee=W["ee"], lsham=W["lsham"], eeo=W["eeo"], enim=W["enim"], hall=W["hall"], hallo=W["hallo"], hoh=args.hoh)
     ctl = Control(lld=args.lld, nsp=2, recur="block" if args.recur == "block" else "chebyshev")
-    rec = Recursion(ham, lat, ctl, Energy(energy_min=emin, energy_max=emax), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
+    rec = Recursion(ham, lat, ctl, Energy(energy_min=W["emin"], energy_max=W["emax"]), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
     if args.kernels:
         rec.set_option("kernels", args.kernels)
     if args.batch:
@@ -335,8 +408,7 @@ def main():
             assert np.abs(a_img[other]).max() > 0, "gathered image has no data from the other ranks"
 
     if rank == 0:
-        variant = ("hoh " if args.hoh else "") + ("spin-mixing " if args.spin_mixing else "")
-        wl_key = "%s%s%s_c%d_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", "_mix" if args.spin_mixing else "", n, args.sites, args.lld)
+        wl_key = W["key"]
         tuned = bool(args.kernels or args.batch or args.no_positions or args.opt)
         # algorithmic work (reference semantics: only blocks whose source atom is inside the active region are multiplied)
         flop_rank = FLOP_PER_BLOCK_MULT * (tm_acc["block_multiplies"] + POST_FLOP_BLOCKS[args.recur] * tm_acc["atom_steps"])
@@ -373,9 +445,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic periodic bcc lattice; physical Fe spd stencil (18x18 complex blocks) dumped from the reference's bulk/bccFe case",
-            "config": {"workload": "bcc Fe %d^3 = %d atoms, nsp=2 18x18 blocks, %s%s LL=%d, %d sites per GPU per step"
-                                   % (n, kk, variant, "block Lanczos" if args.recur == "block" else "Chebyshev", args.lld, args.sites),
+            "data": W["data"],
+            "config": {"workload": W["name"],
                        "workload_key": wl_key, "sites_per_gpu": args.sites, "atoms": kk, "lld": args.lld,
                        "parallelism": "site-partition x%d (get_mpi_variables rule), no collective in the loop" % world,
                        "collective": None if world == 1 else "%s all-reduce of the zero-padded per-site image on the %s" % (backend, "host (rehearsal)" if rehearsal else "device")},
@@ -414,7 +485,7 @@ def main():
                 print("LDOS stage skipped: %r" % (e,), file=sys.stderr)
         if world == 1 and not args.no_cpu:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            cb = cpu_baseline(nn, st, args.lld, threads, args.recur, args.hoh, emin, emax)
+            cb = cpu_baseline(W, args.lld, threads, args.recur, args.hoh)
             if cb:
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)

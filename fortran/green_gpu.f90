@@ -29,10 +29,17 @@ module green_gpu_mod
    private
 
    type, public, extends(green) :: green_gpu
+      !> `g0` on demand: with defer_g0 = .true. `block_green` only notes that `g0` is out of date; the continued fraction and the
+      !> 13 MB per site it brings over PCIe happen in `fetch_g0`, which the consumers of `g0` call (bands_gpu does before every
+      !> inherited routine that reads it).  A flow that only needs densities of states (`bands_gpu%calculate_fermi`, served by the
+      !> device LDOS stage from the coefficients the recursion left on the GPU) then never produces `g0` at all.
+      logical :: defer_g0 = .false.
+      logical :: g0_stale = .false.
    contains
       procedure :: bgreen => gpu_bgreen
       procedure :: block_green => gpu_block_green
       procedure :: chebyshev_green => gpu_chebyshev_green
+      procedure :: fetch_g0 => gpu_fetch_g0
    end type green_gpu
 
    interface green_gpu
@@ -106,6 +113,11 @@ contains
       real(rp), allocatable, target :: ene(:), ai(:, :, :), bi(:, :, :)
       complex(rp), allocatable, target :: ab(:, :, :, :), bs(:, :, :, :), gt(:, :, :, :)
 
+      if (this%defer_g0 .and. .not. this%g0_stale) then
+         this%g0_stale = .true.                               ! produced by fetch_g0 when somebody reads g0
+         return
+      end if
+      this%g0_stale = .false.
       ll = this%control%lld
       ldim = 18
       nw = 10*ll
@@ -144,6 +156,13 @@ contains
       call g_timer%stop('bgreen-gpu')
       if (rc /= 0) call g_logger%fatal('rsrec_block_green: '//rsrec_error_string(handle), __FILE__, __LINE__)
    end subroutine gpu_block_green
+
+   !> `g0` of the last (deferred) `block_green` call, now.  A no-op when `g0` is up to date.
+   subroutine gpu_fetch_g0(this)
+      class(green_gpu), intent(inout) :: this
+      if (.not. this%g0_stale) return
+      call this%block_green()                                ! g0_stale is set: this call does the work
+   end subroutine gpu_fetch_g0
 
    !> Replaces green.f90:1030-1108: g0 of the sites of this rank from the Chebyshev moments.  The side effect of the reference
    !> routine -- recursion%mu_ng = mu_n * Jackson kernel (* 2 beyond the first moment), read later by bands.f90:762 -- is kept.

@@ -56,10 +56,13 @@ module recursion_gpu_mod
       procedure :: gpu_constructor
    end interface recursion_gpu
 
-   public :: rsrec_gpu_shutdown, rsrec_gpu_context
+   public :: rsrec_gpu_shutdown, rsrec_gpu_context, rsrec_gpu_block_resident
 
    !> the per-process device context (lazy)
    type(c_ptr), save :: g_handle = c_null_ptr
+   !> number of sites whose block coefficients the last driver call left on the device (0: none -- another driver ran since, or the
+   !> coefficients there are not the ones in a_b / b2_b, as after a local-axis run): the input of the device LDOS stage
+   integer, save :: g_block_resident = 0
 
 contains
 
@@ -88,6 +91,12 @@ contains
       end if
       handle = g_handle
    end function rsrec_gpu_context
+
+   !> Sites of this rank whose a_b / b2_b (as recur_b produced them) are also resident on the device; 0 if they are not.
+   function rsrec_gpu_block_resident() result(n)
+      integer :: n
+      n = g_block_resident
+   end function rsrec_gpu_block_resident
 
    subroutine check(rc, where)
       integer(c_int), intent(in) :: rc
@@ -180,6 +189,7 @@ contains
       call get_mpi_variables(rank, this%lattice%nrec)            ! recursion.f90:1816
       llmax = this%lattice%control%lld
       nloc = end_atom - start_atom + 1
+      g_block_resident = 0
       if (nloc <= 0) return
       allocate (seeds(nloc), ab(18, 18, llmax, nloc), bb(18, 18, llmax, nloc))
 
@@ -217,6 +227,7 @@ contains
          rc = rsrec_block_lanczos(g_handle, int(nloc, c_int), c_loc(seeds), int(llmax, c_int), c_loc(ab), c_loc(bb))
          call g_timer%stop('H|PSI_n>')
          call check(rc, 'rsrec_block_lanczos')
+         g_block_resident = nloc
       end if
 
       do i_loc = 1, nloc                                          ! recursion.f90:1844-1853
@@ -280,6 +291,7 @@ contains
       if (nch == 0) return
       allocate (ab(18, 18, llmax, nch), bb(18, 18, llmax, nch))
       call sync_device(this, .true.)
+      g_block_resident = 0
       rc = rsrec_block_lanczos_seeded(g_handle, int(nch, c_int), 2_c_int, c_loc(seeds), c_loc(coef), int(llmax, c_int), c_loc(ab), c_loc(bb))
       call check(rc, 'rsrec_block_lanczos_seeded')
       do c = 1, nch
@@ -335,6 +347,7 @@ contains
       end do
       call sync_device(this, .true.)
       call g_timer%start('<PSI_0|PSI_n>')
+      g_block_resident = 0
       rc = rsrec_chebyshev(g_handle, int(nloc, c_int), c_loc(seeds), int(this%control%lld, c_int), real(a, c_double), real(b, c_double), c_loc(mu))
       call g_timer%stop('<PSI_0|PSI_n>')
       call check(rc, 'rsrec_chebyshev')
@@ -380,6 +393,7 @@ contains
       end do
       call sync_device(this, .true.)
       call g_timer%start('<PSI_0|PSI_n>')
+      g_block_resident = 0
       rc = rsrec_chebyshev_seeded(g_handle, int(nch, c_int), 2_c_int, c_loc(seeds), c_loc(coef), int(this%control%lld, c_int), &
                                   real(a, c_double), real(b, c_double), c_loc(mu))
       call g_timer%stop('<PSI_0|PSI_n>')
@@ -407,6 +421,7 @@ contains
          seeds(g2l_map(i)) = int(this%lattice%irec(i), c_int)
       end do
       call sync_device(this, .true.)
+      g_block_resident = 0
       rc = rsrec_scalar_lanczos(g_handle, int(nloc, c_int), c_loc(seeds), int(this%lattice%control%lld, c_int), int(llmax_a, c_int), c_loc(a), c_loc(b2))
       call check(rc, 'rsrec_scalar_lanczos')
       ! the reference fills rows 1..lld of a(:,:,i_loc,1) / b2 and leaves the rest untouched (:3516-3519)

@@ -219,7 +219,7 @@ int rsrec_set_option(rsrec_t *h, const char *key, long value);
  *   out[5] ms in the remaining recursion kernels, out[6] host ms (region bookkeeping + transfers),
  *   out[7] 1 if the timed H|psi> kernel also forms the A_n partial (VALU / fused variants), else 0,
  *   out[8] matrix flops EXECUTED by the timed k_spmm5 launches (padding of the MFMA tiles included, structural zeros of spin-diagonal
- *          blocks not: they are skipped), counted for the operator class of the last atom type; 0 for the other kernels.
+ *          blocks not: they are skipped), per operator class of the groups; 0 for the other kernels.
  *   out[9] flops of the H|psi> applications that the operator's BLOCK STRUCTURE requires: out[4] counts the reference's zgemm on full
  *          18x18 blocks (46 656 flop each, recursion.f90:1618); a spin-diagonal block (every hopping block of a collinear magnet,
  *          hamiltonian.f90:1553-1617) needs 23 328, a spin-mixing block 46 656 -- the unit roofline fractions are quoted in.

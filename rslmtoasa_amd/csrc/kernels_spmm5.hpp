@@ -242,8 +242,6 @@ struct Spmm5Operator {
             if (ksteps[(size_t)set * ntau + tau] > 0) { if (one >= 0) return -1; one = tau; }
         return one;
     }
-    // matrix flops one group of 8 atoms costs in set `set` (both spin waves; class of the last atom type -- the bulk atoms): per k-step
-    // nine tiles of one 16x16x4 and one 4x4x4 (4 blocks) MFMA
     // flops the block structure REQUIRES for one multiplication by block (set, tau, slot): a spin-diagonal block (hopping block of a
     // collinear magnet, hamiltonian.f90:1553-1617) is two 9x9 complex quadrants = half of the reference's 18x18x18 zgemm (recursion.f90:1618)
     double required_flops(int set, int tau, int slot) const {
@@ -251,7 +249,9 @@ struct Spmm5Operator {
         if (q >= mixing.size() || mixing[q] < 0) return 0.0;
         return mixing[q] ? 46656.0 : 23328.0;
     }
-    double flops_per_group(int set) const { return ksteps.empty() ? 0.0 : 2.0 * ksteps[(size_t)set * ntau + ntau - 1] * 9.0 * (2.0 * 16 * 16 * 4 + 2.0 * 4 * 4 * 4 * 4); }
+    // matrix flops one group of 8 atoms of operator class tau costs in set `set` (both spin waves): per k-step nine tiles of one 16x16x4
+    // and one 4x4x4 (4 blocks) MFMA
+    double flops_per_group(int set, int tau) const { return ksteps.empty() ? 0.0 : 2.0 * ksteps[(size_t)set * ntau + tau] * 9.0 * (2.0 * 16 * 16 * 4 + 2.0 * 4 * 4 * 4 * 4); }
     const double* frag_set(int set) const { return d_frag + (size_t)set * ntau * 2 * ntr * S5_TRIPLE; }
     const int* meta_set(int set) const { return d_meta + (size_t)set * ntau * META; }
 };

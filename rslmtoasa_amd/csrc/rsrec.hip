@@ -123,7 +123,7 @@ struct rsrec_handle {
         double atom_steps, block_mults;
         DevBuf order, cum;
         std::vector<int> level_max;     // per level: largest active-atom count over the chains of this entry
-        std::vector<double> level_groups;   // per level: groups of 8 atoms (padding included) summed over the chains
+        std::vector<double> level_groups;   // [level][tau]: groups of 8 atoms (padding included) of operator class tau, summed over the chains
         std::vector<double> mult_hist;      // [pass 0/1][tau][nslots + 1]: block multiplications of the call by (pass, operator class, slot), summed over the chains
     };
     std::vector<RegionEntry*> region_cache;
@@ -749,12 +749,24 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     XFER(xfer_h2d(h, e->cum.p, cum.data(), cum.size() * 4));
     HIPCK(h, hipStreamSynchronize(h->stream));   // order/cum are stack-local vectors
     e->level_max.assign(nlev, 0);
-    e->level_groups.assign(nlev, 0.0);
-    for (int c = 0; c < nb; ++c)
-        for (int l = 0; l < nlev; ++l) {
-            e->level_max[l] = std::max(e->level_max[l], cum[(size_t)c * nlev + l]);
-            e->level_groups[l] += cum[(size_t)c * nlev + l] / GROUP;
+    e->level_groups.assign((size_t)nlev * ntau_h, 0.0);
+    {
+        // groups by operator class: the saturated list is the same for every chain; a level-major list is walked once per chain
+        std::vector<double> sat_hist(ntau_h, 0.0), run(ntau_h, 0.0);
+        for (int g = 0; g < sat_count / GROUP; ++g) sat_hist[tau(sat_list[(size_t)g * GROUP])] += 1.0;
+        for (int c = 0; c < nb; ++c) {
+            const int* orow = order.data() + (size_t)c * ostride;
+            std::fill(run.begin(), run.end(), 0.0);
+            int g = 0;
+            for (int l = 0; l < nlev; ++l) {
+                const int cnt = cum[(size_t)c * nlev + l];
+                e->level_max[l] = std::max(e->level_max[l], cnt);
+                const bool sat = cum[(size_t)(nb + c) * nlev + l] != 0;
+                if (!sat) for (; g < cnt / GROUP; ++g) run[grouped ? tau(orow[(size_t)g * GROUP]) : 0] += 1.0;
+                for (int t2 = 0; t2 < ntau_h; ++t2) e->level_groups[(size_t)l * ntau_h + t2] += sat ? sat_hist[t2] : run[t2];
+            }
         }
+    }
     h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
     h->cur_mult_hist = &e->mult_hist;
     return RSREC_OK;
@@ -899,8 +911,8 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
         k_spmm5<TWO, true><<<g2, thr, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
         k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0, nullptr, 1, epi);
-    if (h->cur_level_groups && SD.level >= 0 && SD.level < (int)h->cur_level_groups->size() && SD.cpo == 1)
-        h->n_hop_mfma_flop += (*h->cur_level_groups)[SD.level] * op.flops_per_group(set);
+    if (h->cur_level_groups && SD.level >= 0 && (size_t)(SD.level + 1) * op.ntau <= h->cur_level_groups->size() && SD.cpo == 1 && op.ntau == h->nmax + h->ntype)
+        for (int t = 0; t < op.ntau; ++t) h->n_hop_mfma_flop += (*h->cur_level_groups)[(size_t)SD.level * op.ntau + t] * op.flops_per_group(set, t);
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)

@@ -9,6 +9,12 @@
 ! which now dispatch to the HIP kernels.  Used as the end-to-end drop-in test: the outputs (<label>_out.nml,
 ! totaldos.out) are compared with the reference's committed tests/scf/references/*/ref.json values.
 ! Run inside a scratch copy of a case directory; reads input.nml.
+!
+! Environment (tests/test_fortran_dropin.py):
+!   RSREC_HOST_LDOS=1   bands_gpu%device_ldos = F: calculate_fermi sums a downloaded g0 on the host (the inherited routine)
+!   RSREC_DEFER_G0=1    green_gpu%defer_g0 = T: g0 is produced only when a routine reads it
+!   RSREC_LDOS_ONLY=1   no SCF loop: one recursion + the density-of-states stage (the call sequence of self.f90:769-806, :821-833 and
+!                       calculation.f90:700-712 up to calculate_fermi), then the timer report; with RSREC_DEFER_G0=1 no g0 exists at all
 !------------------------------------------------------------------------------
 program scf_gpu_driver
    use mpi_mod
@@ -24,6 +30,7 @@ program scf_gpu_driver
    use green_mod
    use green_gpu_mod
    use bands_mod
+   use bands_gpu_mod
    use self_mod
    use calculation_mod
    use symbolic_atom_mod, only: save_state
@@ -40,9 +47,12 @@ program scf_gpu_driver
    type(recursion_gpu), target :: recursion_obj
    type(green_gpu), target :: green_obj      ! <-- second drop-in: the Green function of the block recursion on the GPU
    type(dos), target :: dos_obj
-   type(bands), target :: bands_obj
+   type(bands_gpu), target :: bands_obj      ! <-- the density-of-states reduction of calculate_fermi on the GPU, g0 on demand
    type(mix), target :: mix_obj
    character(len=32) :: pre
+   character(len=8) :: envv
+   integer :: ia, elen, estat
+   logical :: ldos_only
 
    rank = 0
    numprocs = 1
@@ -96,13 +106,45 @@ program scf_gpu_driver
    ! bands' constructor takes a non-polymorphic `type(green)` dummy (bands.f90:121); in the reference itself that dummy
    ! becomes `class(green)` (INTEGRATION.md).  With the reference's object code as it is, the parent component is passed
    ! and the class pointer re-pointed at the whole object, which is what the polymorphic dummy would have done.
-   bands_obj = bands(green_obj%green)
-   bands_obj%green => green_obj
-   self_obj = self(bands_obj, mix_obj)
-   call g_timer%start('self-consistency')
-   call self_obj%run()
-   call g_timer%stop('self-consistency')
-   call save_state(lattice_obj%symbolic_atoms)
+   bands_obj = bands_gpu(green_obj)
+   call get_environment_variable('RSREC_HOST_LDOS', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) bands_obj%device_ldos = .false.
+   call get_environment_variable('RSREC_DEFER_G0', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) green_obj%defer_g0 = .true.
+   call get_environment_variable('RSREC_LDOS_ONLY', envv, elen, estat)
+   ldos_only = estat == 0 .and. elen > 0
+   ! self's constructor has the same non-polymorphic dummy (self.f90:262): parent component in, class pointer re-pointed
+   self_obj = self(bands_obj%bands, mix_obj)
+   self_obj%bands => bands_obj
+   if (ldos_only) then
+      ! one recursion and the density-of-states stage, no atomic-sphere step (run_recursion self.f90:769-806; run_dos :821-833)
+      call g_timer%start('ldos-only')
+      select case (control_obj%calctype)
+      case ('B')
+         do ia = 1, lattice_obj%nrec
+            call lattice_obj%symbolic_atoms(ia)%build_pot()
+         end do
+      case default
+         do ia = 1, lattice_obj%ntype
+            call lattice_obj%symbolic_atoms(ia)%build_pot()
+         end do
+      end select
+      if (control_obj%nsp == 2 .or. control_obj%nsp == 4) call hamiltonian_obj%build_lsham
+      call hamiltonian_obj%build_bulkham()
+      if (control_obj%calctype == 'I') call hamiltonian_obj%build_locham()
+      call recursion_obj%recur_b()
+      call energy_obj%e_mesh()
+      call recursion_obj%zsqr()
+      call green_obj%block_green()
+      call bands_obj%calculate_fermi()
+      call g_timer%stop('ldos-only')
+      write (*, '(a,i0,a,l1)') 'ldos-only: device_ldos_calls=', bands_obj%n_device_ldos, ' g0_pending=', green_obj%g0_stale
+   else
+      call g_timer%start('self-consistency')
+      call self_obj%run()
+      call g_timer%stop('self-consistency')
+      call save_state(lattice_obj%symbolic_atoms)
+   end if
    call g_timer%stop('Calculation')
    call g_timer%print_report()
    call rsrec_gpu_shutdown()

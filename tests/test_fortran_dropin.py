@@ -64,6 +64,9 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
         # block recursions: the Green function (green%bgreen) also ran on the GPU (fortran/green_gpu.f90); its timer region is
         # listed in the reference's own timing report
         assert "bgreen-gpu" in log, log[-3000:]
+        # ... and the densities of states of calculate_fermi (totaldos.out below) came from the device LDOS stage
+        # (fortran/bands_gpu.f90) except in local-axis runs, whose resident coefficients are the un-rotated ones
+        assert ("ldos-gpu" in log) == ("local_axis" not in str(case["patch"])), log[-3000:]
     if "'chebyshev'" in str(case["patch"]) and "exe" not in case:
         assert "chebyshev-green-gpu" in log, log[-3000:]
     at, rt = case["abs_tol"], case["rel_tol"]
@@ -88,3 +91,40 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
                 if not close(got, e, at, rt):
                     bad.append((fn, row, col, got, e))
     assert not bad, bad
+
+
+LDOS_CASES = ["Example_bulk_bccFe_nsp2_block", "Example_impurity_B2FeCo_block_hoh", "Example_surface_fccCu001_block_hoh"]
+
+
+@pytest.mark.parametrize("name", LDOS_CASES)
+def test_density_of_states_without_g0(name, tmp_path):
+    """A flow that stops at the densities of states (recur_b -> zsqr -> block_green -> calculate_fermi: calculation.f90:700-712,
+    self.f90:821-833) with `bands_gpu` + `green_gpu%defer_g0`: dtot / dosia / dosial come from rsrec_block_ldos on the coefficients
+    the recursion left on the device, and g0 (13 MB per site) is never produced.  Checked against the same flow with the reference's
+    own host reduction over a downloaded g0: the three files the reference writes must agree to the printed digits."""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/rslmto_gpu.x not built (needs the reference sources: build container only)")
+    case = MANIFEST[name]
+    outs = {}
+    for mode, env in (("device", {"RSREC_LDOS_ONLY": "1", "RSREC_DEFER_G0": "1"}), ("host", {"RSREC_LDOS_ONLY": "1", "RSREC_HOST_LDOS": "1"})):
+        work = tmp_path / mode
+        shutil.copytree(os.path.join(SCF, case["inputs"]), work)
+        inp = work / "input.nml"
+        inp.write_text(patch_namelist(inp.read_text(), case["patch"]))
+        r = run_with_unlimited_stack([EXE], cwd=work, env=dict(env, OMP_NUM_THREADS="8"), timeout=1500, scrub=False)
+        log = r.stdout + r.stderr
+        assert r.returncode == 0 and "fatal" not in log.lower(), log[-3000:]
+        if mode == "device":
+            assert "ldos-only: device_ldos_calls=1 g0_pending=T" in log, log[-2000:]
+            assert "ldos-gpu" in log and "bgreen-gpu" not in log, log[-3000:]            # no Green-function download in this flow
+        else:
+            assert "ldos-only: device_ldos_calls=0 g0_pending=F" in log, log[-2000:]
+            assert "bgreen-gpu" in log and "ldos-gpu" not in log, log[-3000:]
+        outs[mode] = {fn: [[fortran_float(v) for v in line.split()] for line in (work / fn).read_text().splitlines()]
+                      for fn in sorted(os.listdir(work)) if fn == "totaldos.out" or fn.endswith("_dos.out")}
+    assert set(outs["device"]) == set(outs["host"]) and len(outs["device"]) >= 3
+    for fn, rows in outs["device"].items():
+        ref = outs["host"][fn]
+        assert len(rows) == len(ref) > 1000, fn
+        worst = max(abs(a - b) for ra, rb in zip(rows, ref) for a, b in zip(ra, rb))
+        assert worst <= 1.0e-5 + 1e-12, (fn, worst)                                      # files carry 5 decimals: last-digit rounding at most
