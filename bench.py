@@ -368,8 +368,7 @@ def main():
             if args.recur == "block":
                 rec.pack_diag(start - 1, nsites_total, img[0].data_ptr(), img[1].data_ptr())
             else:
-                img.zero_()
-                img[start - 1:end].copy_(torch.from_numpy(np.ascontiguousarray(rec.mu_n[:, :, :, :end - start + 1].T).view(np.float64).reshape(end - start + 1, 2 * args.lld + 2, 18, 18, 2)))
+                rec.pack_moments(start - 1, nsites_total, img.data_ptr())        # mu_n of this rank's sites into the zero image, on the device
             if rehearsal:
                 hostimg = img.cpu()
                 dist.all_reduce(hostimg, op=dist.ReduceOp.SUM)

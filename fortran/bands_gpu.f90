@@ -110,7 +110,7 @@ contains
    subroutine gpu_calculate_fermi(this)
       class(bands_gpu) :: this
       integer :: nv, nrec, ia, ik1, ik1_mag, ifail
-      integer(c_int) :: rc, sym_i
+      integer(c_int) :: rc, sym_i, crank, cranks
       type(c_ptr) :: handle
       real(rp) :: e1, e1_mag, ef_mag
       real(rp), allocatable, target :: ene(:), dtot(:), dosia(:, :), dosial(:, :, :)
@@ -140,11 +140,23 @@ contains
 
       this%qqv = real(sum(this%symbolic_atom(1:this%lattice%nbulk_bulk)%element%valence))      ! bands.f90:251
       if (rank == 0) call g_logger%info('Valence is:'//fmt('f16.6', this%qqv), __FILE__, __LINE__)
+      ! the all-reduce of bands.f90:271-274: over the library's own communicator if the host set one up (rsrec_comm_init[_file]: RCCL
+      ! over xGMI, no MPI needed), else the reference's MPI calls
+      rc = rsrec_comm_size(handle, crank, cranks)
+      if (cranks > 1) then
+         dtot = this%dtot(1:nv)
+         rc = rsrec_allreduce_sum(handle, c_loc(dtot), int(nv, c_size_t))
+         if (rc == 0) rc = rsrec_allreduce_sum(handle, c_loc(dosia), int(size(dosia), c_size_t))
+         if (rc == 0) rc = rsrec_allreduce_sum(handle, c_loc(dosial), int(size(dosial), c_size_t))
+         if (rc /= 0) call g_logger%fatal('rsrec_allreduce_sum: '//rsrec_error_string(handle), __FILE__, __LINE__)
+         this%dtot(1:nv) = dtot
+      else
 #ifdef USE_MPI
       call MPI_ALLREDUCE(MPI_IN_PLACE, this%dtot, nv, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, ierr)       ! bands.f90:271-274
       call MPI_ALLREDUCE(MPI_IN_PLACE, dosia, size(dosia), MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, ierr)
       call MPI_ALLREDUCE(MPI_IN_PLACE, dosial, size(dosial), MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_WORLD, ierr)
 #endif
+      end if
       ! output files of bands.f90:279-324 (same names, units, formats; every rank replaces totaldos.out, rank 0 fills the files)
       call write_columns(125, 'totaldos.out', nv, this%en%ene(1:nv) - this%en%fermi, reshape(this%dtot(1:nv), [1, nv]), rank == 0, .true.)
       do ia = 1, nrec

@@ -193,6 +193,59 @@ module rsrec_binding
          integer(c_int), intent(out) :: start_atom, end_atom
       end subroutine
 
+      function rsrec_pack_moments(handle, site_offset, nsites_total, mu_img) bind(C, name='rsrec_pack_moments') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: site_offset, nsites_total
+         type(c_ptr), value :: mu_img
+         integer(c_int) :: rc
+      end function
+
+      ! library-level communicator (RCCL inside librsrec; include/rsrec.h): the MPI_ALLREDUCE(MPI_IN_PLACE, ..., MPI_SUM) of
+      ! bands.f90:271-274 without MPI on the host
+      function rsrec_comm_unique_id(id) bind(C, name='rsrec_comm_unique_id') result(rc)
+         import :: c_int, c_char
+         character(kind=c_char), intent(out) :: id(*)          ! 128 bytes
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_comm_init(handle, rank, nranks, id) bind(C, name='rsrec_comm_init') result(rc)
+         import :: c_int, c_ptr, c_char
+         type(c_ptr), value :: handle
+         integer(c_int), value :: rank, nranks
+         character(kind=c_char), intent(in) :: id(*)
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_comm_init_file(handle, rank, nranks, path, timeout_s) bind(C, name='rsrec_comm_init_file') result(rc)
+         import :: c_int, c_ptr, c_char, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: rank, nranks
+         character(kind=c_char), intent(in) :: path(*)         ! NUL-terminated
+         real(c_double), value :: timeout_s
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_allreduce_sum(handle, buf, n) bind(C, name='rsrec_allreduce_sum') result(rc)
+         import :: c_int, c_ptr, c_size_t
+         type(c_ptr), value :: handle, buf
+         integer(c_size_t), value :: n
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_comm_size(handle, rank, nranks) bind(C, name='rsrec_comm_size') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), intent(out) :: rank, nranks
+         integer(c_int) :: rc
+      end function
+
+      function rsrec_comm_destroy(handle) bind(C, name='rsrec_comm_destroy') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int) :: rc
+      end function
+
       function rsrec_last_error(handle, buf, n) bind(C, name='rsrec_last_error') result(rc)
          import :: c_int, c_ptr, c_char, c_size_t
          type(c_ptr), value :: handle

@@ -200,6 +200,29 @@ void rsrec_site_partition(int rank, int nprocs, int nsites, int *start_atom, int
 /* Last error text of this handle (NUL-terminated, truncated to n). */
 int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
 
+/* The Chebyshev counterpart of rsrec_pack_diag: the moments mu_n(18,18,2 lld + 2,site) of the last rsrec_chebyshev call, as they lie on
+ * the device, inside a zero image over all sites (shape (18,18,2 lld + 2,nsites_total) complex; device or host memory) -- the buffer a
+ * sum all-reduce turns into the all-gather of recursion.f90:1790-1793 (commented-out MPI_Allgather of the coefficients). */
+int rsrec_pack_moments(rsrec_t *h, int site_offset, int nsites_total, double *mu_img);
+
+/* Library-level communicator: the one exchange of the path -- MPI_ALLREDUCE(MPI_IN_PLACE, ..., MPI_SUM) on zero-padded per-site arrays
+ * (bands.f90:271-274; sites are dealt to the ranks by mpi.f90:32-58 = rsrec_site_partition) -- as ONE RCCL all-reduce over xGMI,
+ * without MPI or torch on the host.  RCCL is bound with dlopen on first use.  One rank per GPU; the handle's device is the rank's GPU.
+ *   rsrec_comm_unique_id : one rank creates the id (RSREC_COMM_ID_BYTES bytes) and hands it to the others (MPI_Bcast, a file, ...)
+ *   rsrec_comm_init      : collective; same id on every rank
+ *   rsrec_comm_init_file : the same with the id exchanged through `path` (rank 0 writes it, the others wait up to timeout_s seconds)
+ *   rsrec_allreduce_sum  : in-place sum of n doubles over the ranks; buf = device memory (the images of rsrec_pack_diag /
+ *                          rsrec_pack_moments / rsrec_block_ldos, reduced where they lie) or host memory (staged).  Identity without a
+ *                          communicator, like the reference built without MPI.
+ *   rsrec_comm_size      : rank and number of ranks of the handle's communicator (0, 1 without one) */
+#define RSREC_COMM_ID_BYTES 128
+int rsrec_comm_unique_id(char *id);
+int rsrec_comm_init(rsrec_t *h, int rank, int nranks, const char *id);
+int rsrec_comm_init_file(rsrec_t *h, int rank, int nranks, const char *path, double timeout_s);
+int rsrec_allreduce_sum(rsrec_t *h, double *buf, size_t n);
+int rsrec_comm_size(rsrec_t *h, int *rank, int *nranks);
+int rsrec_comm_destroy(rsrec_t *h);
+
 /* ---- tuning / measurement (not part of the reference interface) ---- */
 /* key/value knobs (defaults in brackets; everything but "batch" and "kernels" exists for A/B measurements and tests):
  *   "batch"      chains advanced together per launch [0 = auto: up to 64, bounded by free device memory]

@@ -26,6 +26,13 @@ _SIGNATURES = {
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_block_lanczos_local_axis": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_pack_diag": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rsrec_pack_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rsrec_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rsrec_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "rsrec_comm_init_file": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_double]),
+    "rsrec_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rsrec_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rsrec_comm_destroy": (C.c_int, [C.c_void_p]),
     "rsrec_terminator": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "rsrec_block_ldos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "rsrec_kubo_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 5),

@@ -97,7 +97,7 @@ struct rsrec_handle {
     DevBuf d_bsqrt, d_term, d_gim, d_ldos;   // LDOS stage on resident coefficients: sqrt(B^2), terminators, Im g0_jj, output images
     void* pin = nullptr;              // pinned host staging buffer: every per-call transfer goes through it (see xfer_*)
     size_t pin_bytes = 0;
-    DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal;
+    DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal, d_zsqr;
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
@@ -135,8 +135,13 @@ struct rsrec_handle {
     const std::vector<double>* cur_mult_hist = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
-    // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root)
+    // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root),
+    // 2 = Chebyshev (d_mu = mu_n of all chains)
     int res_kind = 0, res_n = 0, res_lld = 0, res_sqrt = 0;
+    // library-level communicator (RCCL, bound with dlopen at rsrec_comm_init): the one exchange of the path without MPI or torch
+    void* comm = nullptr;
+    int comm_rank = 0, comm_nranks = 1;
+    DevBuf d_comm;               // staging buffer of rsrec_allreduce_sum on host arrays
 };
 
 namespace {
@@ -333,10 +338,12 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     if (!h) return RSREC_ERR_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)rsrec_comm_destroy(h);
+    h->d_comm.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_s5queue, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_partial2, &h->d_coefA, &h->d_coefB, &h->d_bmats,
-                     &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal};
+                     &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal, &h->d_zsqr};
     for (auto b : all) b->release();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->s4_op.release();
@@ -1363,18 +1370,185 @@ extern "C" int rsrec_pack_diag(rsrec_t* h, int site_offset, int nsites_total, do
     return RSREC_OK;
 }
 
+namespace {
+
+// mu_n(18,18,nmom,site) of this rank's sites inside a zero image over all sites
+__global__ void k_pack_moments(const double2* __restrict__ mu, size_t per_site, int n, int off, int ntot, double2* __restrict__ img) {
+    const size_t total = per_site * (size_t)ntot;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int s = (int)(e / per_site) - off;
+        img[e] = (s >= 0 && s < n) ? mu[(size_t)s * per_site + e % per_site] : make_double2(0.0, 0.0);
+    }
+}
+
+}  // namespace
+
+// The Chebyshev counterpart of rsrec_pack_diag: the moments mu_n(18,18,2 lld + 2,site) of the last rsrec_chebyshev call, as they lie on
+// the device, written into a zero-padded image over all sites (the buffer a sum all-reduce turns into the all-gather the reference's
+// commented-out MPI_Allgather of recursion.f90:1790-1793 describes).  mu_img: device or host memory, complex (18,18,2 lld + 2,nsites_total).
+extern "C" int rsrec_pack_moments(rsrec_t* h, int site_offset, int nsites_total, double* mu_img) {
+    if (!h || !mu_img || site_offset < 0) return fail(h, RSREC_ERR_ARG, "rsrec_pack_moments: bad argument");
+    if (h->res_kind != 2) return fail(h, RSREC_ERR_ARG, "rsrec_pack_moments: no Chebyshev moments resident (call rsrec_chebyshev first)");
+    if (site_offset + h->res_n > nsites_total) return fail(h, RSREC_ERR_ARG, "rsrec_pack_moments: sites %d..%d outside 1..%d", site_offset + 1, site_offset + h->res_n, nsites_total);
+    HIPCK(h, hipSetDevice(h->device));
+    const size_t per_site = (size_t)(2 * h->res_lld + 2) * BLK, n = per_site * nsites_total;
+    const bool dev = is_device_ptr(mu_img);
+    double2* out = reinterpret_cast<double2*>(mu_img);
+    if (!dev) { HIPCK(h, h->d_scal.reserve(n * sizeof(double2))); out = h->d_scal.as<double2>(); }
+    k_pack_moments<<<(int)std::min<size_t>(2048, (n + 255) / 256), 256, 0, h->stream>>>(h->d_mu.as<double2>(), per_site, h->res_n, site_offset, nsites_total, out);
+    HIPCK(h, hipGetLastError());
+    if (!dev) XFER(xfer_d2h(h, mu_img, out, n * sizeof(double2)));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return RSREC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Library-level communicator.  The reference's only exchange on this path is MPI_ALLREDUCE(MPI_IN_PLACE, ..., MPI_SUM) on zero-padded
+// per-site arrays (bands.f90:271-274; mpi.f90:32-58 gives every rank whole sites).  On a node of MI355X this is one RCCL all-reduce
+// over xGMI on a device image; RCCL is bound with dlopen when a communicator is asked for -- the recursion itself does not depend on
+// it -- so a Fortran (or any) host needs neither MPI nor torch for it: the 128-byte id travels by whatever the host has (MPI_Bcast, a
+// file on a shared directory: rsrec_comm_init_file).
+namespace {
+
+struct NcclId { char internal[RSREC_COMM_ID_BYTES]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*get_unique_id)(NcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, NcclId, int) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*get_error_string)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+const char* rccl_ready() {
+    if (g_rccl.lib) return nullptr;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return "RCCL (librccl.so) not found";
+    g_rccl.get_unique_id = reinterpret_cast<decltype(g_rccl.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.comm_init_rank = reinterpret_cast<decltype(g_rccl.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.all_reduce = reinterpret_cast<decltype(g_rccl.all_reduce)>(dlsym(lib, "ncclAllReduce"));
+    g_rccl.comm_destroy = reinterpret_cast<decltype(g_rccl.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.get_error_string = reinterpret_cast<decltype(g_rccl.get_error_string)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) return "RCCL symbols missing";
+    g_rccl.lib = lib;
+    return nullptr;
+}
+const char* rccl_err(int rc) { return g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "RCCL error"; }
+
+}  // namespace
+
+// id: RSREC_COMM_ID_BYTES bytes; created by ONE rank and given to all (ncclGetUniqueId).
+extern "C" int rsrec_comm_unique_id(char* id) {
+    if (!id) return RSREC_ERR_ARG;
+    if (rccl_ready()) return RSREC_ERR_DEVICE;
+    NcclId u;
+    if (g_rccl.get_unique_id(&u) != 0) return RSREC_ERR_DEVICE;
+    memcpy(id, u.internal, RSREC_COMM_ID_BYTES);
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_comm_destroy(rsrec_t* h) {
+    if (!h) return RSREC_ERR_ARG;
+    if (h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)g_rccl.comm_destroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->comm_rank = 0; h->comm_nranks = 1;
+    return RSREC_OK;
+}
+
+// Collective over all ranks: every rank calls it with the same id and its own rank; the handle's device is the rank's GPU.
+extern "C" int rsrec_comm_init(rsrec_t* h, int rank, int nranks, const char* id) {
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, RSREC_ERR_ARG, "rsrec_comm_init: bad argument");
+    if (const char* msg = rccl_ready()) return fail(h, RSREC_ERR_DEVICE, "rsrec_comm_init: %s", msg);
+    (void)rsrec_comm_destroy(h);
+    HIPCK(h, hipSetDevice(h->device));
+    NcclId u;
+    memcpy(u.internal, id, RSREC_COMM_ID_BYTES);
+    const int rc = g_rccl.comm_init_rank(&h->comm, nranks, u, rank);
+    if (rc != 0) { h->comm = nullptr; return fail(h, RSREC_ERR_DEVICE, "ncclCommInitRank failed: %s", rccl_err(rc)); }
+    h->comm_rank = rank; h->comm_nranks = nranks;
+    return RSREC_OK;
+}
+
+// The same with the id exchanged through a file (hosts without MPI): rank 0 creates the id and publishes it at `path` (written to a
+// temporary name, then renamed: readers never see a partial file); the other ranks wait for it up to `timeout_s` seconds.  `path` must
+// be fresh for every communicator (rank 0 replaces an existing file before the others may read a stale one only if they start later:
+// use a per-job name).
+extern "C" int rsrec_comm_init_file(rsrec_t* h, int rank, int nranks, const char* path, double timeout_s) {
+    if (!h || !path || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, RSREC_ERR_ARG, "rsrec_comm_init_file: bad argument");
+    char id[RSREC_COMM_ID_BYTES];
+    if (rank == 0) {
+        if (rsrec_comm_unique_id(id) != RSREC_OK) return fail(h, RSREC_ERR_DEVICE, "rsrec_comm_init_file: ncclGetUniqueId failed");
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(h, RSREC_ERR_ARG, "rsrec_comm_init_file: cannot write %s", tmp.c_str()); }
+        fclose(f);
+        if (rename(tmp.c_str(), path) != 0) return fail(h, RSREC_ERR_ARG, "rsrec_comm_init_file: cannot publish %s", path);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            FILE* f = fopen(path, "rb");
+            if (f) {
+                const size_t got = fread(id, 1, sizeof id, f);
+                fclose(f);
+                if (got == sizeof id) break;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return fail(h, RSREC_ERR_DEVICE, "rsrec_comm_init_file: no id at %s after %.0f s", path, timeout_s);
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    return rsrec_comm_init(h, rank, nranks, id);
+}
+
+// In-place sum over the ranks of n doubles (the reference's MPI_ALLREDUCE(MPI_IN_PLACE, buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, ...),
+// bands.f90:271-274).  buf: DEVICE memory (the images rsrec_pack_diag / rsrec_pack_moments / rsrec_block_ldos wrote: reduced where they
+// lie, on the engine's stream) or host memory (staged through the device).  Returns when the result is in buf.  Without a communicator
+// (or with one rank) it is the identity, like the reference built without MPI.
+extern "C" int rsrec_allreduce_sum(rsrec_t* h, double* buf, size_t n) {
+    if (!h || (!buf && n > 0)) return fail(h, RSREC_ERR_ARG, "rsrec_allreduce_sum: bad argument");
+    if (n == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    if (!h->comm) { HIPCK(h, hipStreamSynchronize(h->stream)); return RSREC_OK; }
+    const bool dev = is_device_ptr(buf);
+    double* d = buf;
+    if (!dev) {
+        HIPCK(h, h->d_comm.reserve(n * sizeof(double)));
+        d = h->d_comm.as<double>();
+        XFER(xfer_h2d(h, d, buf, n * sizeof(double)));
+    }
+    const int rc = g_rccl.all_reduce(d, d, n, 8 /*ncclDouble*/, 0 /*ncclSum*/, h->comm, h->stream);
+    if (rc != 0) return fail(h, RSREC_ERR_DEVICE, "ncclAllReduce failed: %s", rccl_err(rc));
+    if (!dev) XFER(xfer_d2h(h, buf, d, n * sizeof(double)));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_comm_size(rsrec_t* h, int* rank, int* nranks) {
+    if (!h) return RSREC_ERR_ARG;
+    if (rank) *rank = h->comm_rank;
+    if (nranks) *nranks = h->comm ? h->comm_nranks : 1;
+    return RSREC_OK;
+}
+
 extern "C" int rsrec_zsqr(rsrec_t* h, int nmat, double* b2_b) {
     if (!h || nmat < 0 || (nmat > 0 && !b2_b)) return fail(h, RSREC_ERR_ARG, "rsrec_zsqr: bad argument");
     if (nmat == 0) return RSREC_OK;
     HIPCK(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)nmat * BLK * sizeof(double2);
-    HIPCK(h, h->d_mu.reserve(bytes));
+    HIPCK(h, h->d_zsqr.reserve(bytes));              // (not d_mu: the Chebyshev moments of the last call stay resident there)
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
-    XFER(xfer_h2d(h, h->d_mu.p, b2_b, bytes));
-    k_zsqr<<<nmat, 256, 0, h->stream>>>(h->d_mu.as<double2>(), h->d_status.as<int>());
+    XFER(xfer_h2d(h, h->d_zsqr.p, b2_b, bytes));
+    k_zsqr<<<nmat, 256, 0, h->stream>>>(h->d_zsqr.as<double2>(), h->d_status.as<int>());
     HIPCK(h, hipGetLastError());
-    XFER(xfer_d2h(h, b2_b, h->d_mu.p, bytes));
+    XFER(xfer_d2h(h, b2_b, h->d_zsqr.p, bytes));
     int status = 0;
     XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -1656,18 +1830,19 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     }
     const bool side = h->opt_side && h->side_stream;     // moment reduction of level t under the SpMM of level t + 1 (it feeds nothing on the device)
     bool red_pending = false;
-    HIPCK(h, h->d_mu.reserve((size_t)B * nmom * BLK * sizeof(double2)));
+    h->res_kind = 0;
+    HIPCK(h, h->d_mu.reserve((size_t)nsites * nmom * BLK * sizeof(double2)));      // the moments of ALL chains of the call stay on the device (rsrec_pack_moments)
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)B * (nseed + 1) * sizeof(double2)));
     HIPCK(h, hipMemsetAsync(h->d_status.p, 0, 64, h->stream));
     const DevProblem P = make_problem(h);
     const size_t mstride = (size_t)nmom * BLK;
-    double2* mu = h->d_mu.as<double2>();
     hipEvent_t ev_begin = next_event(h);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> hop_ev;
     for (int c0 = 0; c0 < nsites; c0 += B) {
         const int nb = std::min(B, nsites - c0);
+        double2* mu = h->d_mu.as<double2>() + (size_t)c0 * mstride;       // this batch's slice of the resident moments
         const auto th0 = std::chrono::steady_clock::now();
         std::vector<int> seeds0((size_t)nb * nseed);
         std::vector<double> coef((size_t)nb * nseed * 2 + nb);     // coefficients, then one mu_1 scale per chain
@@ -1786,6 +1961,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     int status = 0;
     XFER(xfer_d2h(h, &status, h->d_status.p, 4));
     if (status & 2) return fail(h, RSREC_ERR_DIVERGED, "Chebyshev moments did not converge. Check energy limits energy_min and energy_max");
+    h->res_kind = 2; h->res_n = nsites; h->res_lld = lld; h->res_sqrt = 0;
     return RSREC_OK;
 }
 

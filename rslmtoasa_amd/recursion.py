@@ -11,6 +11,7 @@ for the reference is the Fortran shim under ``fortran/`` -- this Python mirror e
 and the benchmark read like the reference's own call sites (self.f90:799-806, :829).
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -211,6 +212,41 @@ class Recursion:
         pa = a_img if isinstance(a_img, int) else a_img.ctypes.data
         pb = b2_img if isinstance(b2_img, int) else b2_img.ctypes.data
         self._check(self._L.rsrec_pack_diag(self._h, int(site_offset), int(nsites_total), C.c_void_p(pa), C.c_void_p(pb)))
+
+    def pack_moments(self, site_offset, nsites_total, mu_img):
+        """The Chebyshev counterpart: mu_n(18,18,2 lld + 2,site) of this rank's sites inside a zero image over all sites, written from
+        the moments resident on the device.  mu_img: numpy array or raw (device) address."""
+        pm = mu_img if isinstance(mu_img, int) else mu_img.ctypes.data
+        self._check(self._L.rsrec_pack_moments(self._h, int(site_offset), int(nsites_total), C.c_void_p(pm)))
+
+    # -- library-level communicator (RCCL bound by librsrec itself: no MPI, no torch) -----------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        if _lib.lib().rsrec_comm_unique_id(buf) != 0:
+            raise _lib.RsrecError(2, "rsrec_comm_unique_id failed (RCCL not available?)")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, ident=None, path=None, timeout_s=60.0):
+        """Collective: every rank passes the same 128-byte id (from comm_unique_id on one rank), or a `path` through which rank 0
+        publishes it."""
+        if path is not None:
+            self._check(self._L.rsrec_comm_init_file(self._h, int(rank), int(nranks), os.fsencode(path), float(timeout_s)))
+        else:
+            self._check(self._L.rsrec_comm_init(self._h, int(rank), int(nranks), ident))
+
+    def comm_size(self):
+        r, n = C.c_int(), C.c_int()
+        self._check(self._L.rsrec_comm_size(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def allreduce_sum(self, buf, n=None):
+        """In-place sum over the ranks (bands.f90:271-274): numpy float64 array, or a raw device address with `n` doubles."""
+        if isinstance(buf, int):
+            self._check(self._L.rsrec_allreduce_sum(self._h, C.c_void_p(buf), int(n)))
+        else:
+            assert buf.dtype == np.float64 and buf.flags["C_CONTIGUOUS"] or buf.flags["F_CONTIGUOUS"]
+            self._check(self._L.rsrec_allreduce_sum(self._h, C.c_void_p(buf.ctypes.data), buf.size))
 
     def recur_b_ij(self):
         """Four chains per atom pair, seeds (psi_i +- psi_j)/sqrt2 and (psi_i +- i psi_j)/sqrt2 (recursion.f90:1655-1800)."""

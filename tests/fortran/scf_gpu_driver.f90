@@ -13,6 +13,9 @@
 ! Environment (tests/test_fortran_dropin.py):
 !   RSREC_HOST_LDOS=1   bands_gpu%device_ldos = F: calculate_fermi sums a downloaded g0 on the host (the inherited routine)
 !   RSREC_DEFER_G0=1    green_gpu%defer_g0 = T: g0 is produced only when a routine reads it
+!   RSREC_RANK, RSREC_NRANKS, RSREC_COMM_FILE   a run of several processes WITHOUT MPI: this process is rank RSREC_RANK of RSREC_NRANKS
+!                       (mpi_mod's rank / numprocs, so get_mpi_variables deals the sites), one GPU each, and the densities of states
+!                       are summed over the library's own RCCL communicator whose id travels through the file (rsrec_comm_init_file)
 !   RSREC_LDOS_ONLY=1   no SCF loop: one recursion + the density-of-states stage (the call sequence of self.f90:769-806, :821-833 and
 !                       calculation.f90:700-712 up to calculate_fermi), then the timer report; with RSREC_DEFER_G0=1 no g0 exists at all
 !------------------------------------------------------------------------------
@@ -35,6 +38,8 @@ program scf_gpu_driver
    use calculation_mod
    use symbolic_atom_mod, only: save_state
    use timer_mod, only: g_timer, timer
+   use rsrec_binding
+   use, intrinsic :: iso_c_binding
    implicit none
 
    type(calculation) :: calc_obj
@@ -51,11 +56,16 @@ program scf_gpu_driver
    type(mix), target :: mix_obj
    character(len=32) :: pre
    character(len=8) :: envv
-   integer :: ia, elen, estat
+   character(len=512) :: comm_file
+   integer :: ia, elen, estat, crc
    logical :: ldos_only
 
    rank = 0
    numprocs = 1
+   call get_environment_variable('RSREC_NRANKS', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) read (envv, *) numprocs
+   call get_environment_variable('RSREC_RANK', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) read (envv, *) rank
    g_timer = timer()
    call g_timer%start('Calculation')
 
@@ -113,6 +123,12 @@ program scf_gpu_driver
    if (estat == 0 .and. elen > 0) green_obj%defer_g0 = .true.
    call get_environment_variable('RSREC_LDOS_ONLY', envv, elen, estat)
    ldos_only = estat == 0 .and. elen > 0
+   call get_environment_variable('RSREC_COMM_FILE', comm_file, elen, estat)
+   if (estat == 0 .and. elen > 0) then
+      crc = rsrec_comm_init_file(rsrec_gpu_context(), int(rank, c_int), int(numprocs, c_int), trim(comm_file)//c_null_char, 120.0_c_double)
+      if (crc /= 0) stop 'scf_gpu_driver: rsrec_comm_init_file failed'
+      write (*, '(a,i0,a,i0)') 'library communicator: rank ', rank, ' of ', numprocs
+   end if
    ! self's constructor has the same non-polymorphic dummy (self.f90:262): parent component in, class pointer re-pointed
    self_obj = self(bands_obj%bands, mix_obj)
    self_obj%bands => bands_obj

@@ -106,7 +106,9 @@ def test_density_of_states_without_g0(name, tmp_path):
         pytest.skip("oracle/_ref/rslmto_gpu.x not built (needs the reference sources: build container only)")
     case = MANIFEST[name]
     outs = {}
-    for mode, env in (("device", {"RSREC_LDOS_ONLY": "1", "RSREC_DEFER_G0": "1"}), ("host", {"RSREC_LDOS_ONLY": "1", "RSREC_HOST_LDOS": "1"})):
+    # (the device run also brings up the library's own communicator through a file -- one rank: the box has one GPU)
+    for mode, env in (("device", {"RSREC_LDOS_ONLY": "1", "RSREC_DEFER_G0": "1", "RSREC_RANK": "0", "RSREC_NRANKS": "1", "RSREC_COMM_FILE": str(tmp_path / "comm.id")}),
+                      ("host", {"RSREC_LDOS_ONLY": "1", "RSREC_HOST_LDOS": "1"})):
         work = tmp_path / mode
         shutil.copytree(os.path.join(SCF, case["inputs"]), work)
         inp = work / "input.nml"
@@ -115,7 +117,7 @@ def test_density_of_states_without_g0(name, tmp_path):
         log = r.stdout + r.stderr
         assert r.returncode == 0 and "fatal" not in log.lower(), log[-3000:]
         if mode == "device":
-            assert "ldos-only: device_ldos_calls=1 g0_pending=T" in log, log[-2000:]
+            assert "ldos-only: device_ldos_calls=1 g0_pending=T" in log and "library communicator: rank 0 of 1" in log, log[-2000:]
             assert "ldos-gpu" in log and "bgreen-gpu" not in log, log[-3000:]            # no Green-function download in this flow
         else:
             assert "ldos-only: device_ldos_calls=0 g0_pending=F" in log, log[-2000:]
