@@ -19,6 +19,10 @@ Other workloads of BASELINE.json (same metric, named in config.workload):
   --workload fccCu001     configs[3]: the reference's surface case (tests/scf/cases/surface/fccCu001: fcc Cu(001) slab cluster, 9 318 atoms,
                           THREE atom types, 19 neighbour slots), Chebyshev recursion LL=50, 64 sites; lattice tables and blocks from the
                           committed fixture tests/golden/fccCu001_cheb.npz (the reference holds no Fe(001) case)
+  --workload kubo         stochastic Kubo-Bastin double moments (compute_moments_stochastic, recursion.f90:979): periodic fcc Pt
+                          supercell (--cells, default 20 -> 8 000 atoms) with the blocks and velocity operators of the reference's
+                          conductivity case (tests/golden/fccPt_kubo[_hoh].npz), --cond-ll moment orders (default 50); a step = the
+                          cond_ll x cond_ll moment blocks of one vector: 3 cond_ll whole-lattice SpMMs + the moment GEMMs; single GPU
   --workload B2FeCo       configs[4]: the reference's impurity case (tests/scf/cases/impurity/B2FeCo: 4 152 atoms, nmax = 15 atoms with
                           per-atom `hall` blocks + 3 bulk types), block Lanczos with hoh, LL=50; sites = the 15 impurity-region atoms
                           (per-site LDOS of all inequivalent atoms) + 49 host atoms; fixture tests/golden/B2FeCo_block_hoh.npz
@@ -57,7 +61,8 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=22, help="n for the n^3 periodic bcc supercell")
     ap.add_argument("--lld", type=int, default=50)
     ap.add_argument("--recur", choices=("block", "chebyshev"), default=None, help="default: block (chebyshev for --workload fccCu001)")
-    ap.add_argument("--workload", choices=("bcc", "fccCu001", "B2FeCo"), default="bcc", help="bcc: synthetic periodic bcc Fe supercell (--cells); others: lattices of the reference's own cases")
+    ap.add_argument("--cond-ll", type=int, default=50, help="--workload kubo: moment orders per side")
+    ap.add_argument("--workload", choices=("bcc", "fccCu001", "B2FeCo", "kubo"), default="bcc", help="bcc: synthetic periodic bcc Fe supercell (--cells); others: lattices of the reference's own cases")
     ap.add_argument("--hoh", action="store_true")
     ap.add_argument("--spin-mixing", action="store_true", help="stencil rotated into a tilted spin frame: spin-flip entries in every block")
     ap.add_argument("--kernels", type=int, default=0)
@@ -73,6 +78,8 @@ def parse_args():
         args.recur = "chebyshev" if args.workload == "fccCu001" else "block"
     if args.workload == "B2FeCo":
         args.hoh = True
+    if args.workload == "kubo" and args.cells == 22:
+        args.cells = 20
     return args
 
 
@@ -180,6 +187,103 @@ def build_workload(args, world):
              key="%s%s_%s_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", args.workload, args.sites, args.lld),
              data="lattice tables and Hamiltonian blocks of the reference's own %s case (committed fixture tests/golden/, dumped from the compiled reference)" % args.workload)
     return W
+
+
+FCC_PRIMITIVE = [[0.0, 0.5, 0.5], [0.5, 0.0, 0.5], [0.5, 0.5, 0.0]]      # lattice.f90 bravais, fcc, units of alat
+
+
+def main_kubo(args):
+    """--workload kubo: rsrec_kubo_moments on a periodic fcc Pt supercell (one GPU; the vectors of a real run shard over ranks like sites)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if args.gpus != 1 or os.environ.get("WORLD_SIZE", "1") != "1":
+        print("bench.py: --workload kubo is a single-GPU line", file=sys.stderr)
+        sys.exit(2)
+    from helpers import load_golden
+    from rslmtoasa_amd.lattice import bcc_supercell
+    from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion
+    import rslmtoasa_amd.recursion as R
+    import torch
+    torch.cuda.set_device(0)
+    z = load_golden("fccPt_kubo_hoh" if args.hoh else "fccPt_kubo")
+    n, cond_ll = args.cells, args.cond_ll
+    nn = bcc_supercell((n, n, n), z["slot_vec"], primitive=np.array(FCC_PRIMITIVE))
+    kk, nb = nn.shape[0], int(nn[0, 0])
+    a, b = float(z["acheb"]), float(z["bcheb"])
+    ham = Hamiltonian(ee=z["ee"], lsham=z["lsham"], eeo=z.get("eeo"), enim=z.get("enim"), hoh=args.hoh)
+    lat = Lattice(nn=nn, iz=np.ones(kk, np.int32), irec=np.array([1], np.int32), nmax=0, ntype=1)
+    rec = Recursion(ham, lat, Control(lld=cond_ll, nsp=2), Energy(), device=0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        rec.set_option(k, int(v))
+    R.chebyshev_scaling = lambda emin, emax: (a, b)          # the fixture's window (the mirror would derive it from energy_min / energy_max)
+    vo = dict(vo_a=z.get("vo_a"), vo_b=z.get("vo_b")) if args.hoh else {}
+
+    def step():
+        return rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, atlist=np.array([1], np.int32), **vo)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = {"hop_ms": 0.0, "rest_ms": 0.0, "total_ms": 0.0, "hop_launches": 0.0, "block_multiplies": 0.0, "hop_required_flop": 0.0, "hop_mfma_flop": 0.0}
+    for _ in range(args.steps):
+        mu = step()
+        tm = rec.timing()
+        for k in acc:
+            acc[k] += tm[k]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert np.isfinite(mu).all()
+    gemm_flop = 8.0 * (cond_ll * 18.0) ** 2 * kk * 18.0 * args.steps                 # L^H R over the (atom, row) index: complex MACs x 8
+    spmm_alg = FLOP_PER_BLOCK_MULT * acc["block_multiplies"]
+    hop_s, gemm_s = acc["hop_ms"] * 1e-3, acc["rest_ms"] * 1e-3
+    achieved = acc["hop_required_flop"] / hop_s * 1e-12
+    out = {
+        "metric": "Kubo double-moment throughput (whole-lattice H / velocity SpMMs + moment GEMM, recursion.f90 compute_moments_stochastic)",
+        "value": (spmm_alg + gemm_flop) / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic periodic fcc lattice; Pt spd blocks and velocity operators (v_a, v_b%s) dumped from the reference's conductivity/fccPt case" % (", vo_a, vo_b" if args.hoh else ""),
+        "config": {"workload": "fcc Pt %d^3 = %d atoms, nsp=2 18x18 blocks, %sstochastic Kubo moments cond_ll=%d (%d x %d blocks of 18x18), one vector per step" % (n, kk, "hoh " if args.hoh else "", cond_ll, cond_ll, cond_ll),
+                   "workload_key": "kubo%s_c%d_l%d" % ("_hoh" if args.hoh else "", n, cond_ll), "atoms": kk, "cond_ll": cond_ll, "neighbour_slots": nb,
+                   "parallelism": "single GPU (the vectors of a run shard over ranks like recursion sites)", "collective": None},
+        "vectors_per_s": args.steps / elapsed,
+        "device_ms_per_step": acc["total_ms"] / args.steps,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "frac_kernel": achieved / FP64_PEAK_TFLOPS,
+                     "frac_step": (acc["hop_required_flop"] + gemm_flop) / elapsed * 1e-12 / FP64_PEAK_TFLOPS,
+                     "frac_algorithmic": spmm_alg / hop_s * 1e-12 / FP64_PEAK_TFLOPS, "frac_step_algorithmic": (spmm_alg + gemm_flop) / elapsed * 1e-12 / FP64_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "k_spmm5 (whole-lattice block SpMM: H with the fused Chebyshev step, v_a, v_b)", "launches": acc["hop_launches"],
+                     "avg_launch_ms": acc["hop_ms"] / max(acc["hop_launches"], 1), "share_of_device_time": acc["hop_ms"] / max(acc["total_ms"], 1e-9),
+                     "flops_counted": "required by the block structure (frac, frac_kernel, frac_step); *_algorithmic = 46656 per block multiply",
+                     "executed": {"achieved": acc["hop_mfma_flop"] / hop_s * 1e-12, "frac": acc["hop_mfma_flop"] / hop_s * 1e-12 / FP64_PEAK_TFLOPS, "unit": "TFLOP/s"},
+                     "gemm": {"kernel": "rocBLAS zgemm (L^H R, %d x %d x %d per 64 right vectors)" % (cond_ll * 18, 64 * 18, kk * 18), "ms_per_step": acc["rest_ms"] / args.steps,
+                              "achieved": gemm_flop / gemm_s * 1e-12 if gemm_s > 0 else None, "frac": gemm_flop / gemm_s * 1e-12 / FP64_PEAK_TFLOPS if gemm_s > 0 else None,
+                              "share_of_device_time": acc["rest_ms"] / max(acc["total_ms"], 1e-9)}},
+    }
+    if not args.no_cpu:
+        from rslmtoasa_amd._proc import under_profiler
+        if under_profiler():
+            print("cpu_baseline skipped: running under a profiler", file=sys.stderr)
+        else:
+            # bounded sample: the same lattice and operators at a small moment order on the C restatement (the compiled reference's
+            # compute_moments_stochastic builds its own lattice from a case directory and cannot be fed this table)
+            from oracle import oracle
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+            c_ll = min(cond_ll, 8)
+            prob = dict(nn=nn, iz=np.ones(kk, np.int32), ee=z["ee"], lsham=z["lsham"], hoh=int(args.hoh), nsp=2, nmax=0)
+            if args.hoh:
+                prob.update(eeo=z["eeo"], enim=z["enim"])
+            o = oracle.Oracle(prob)
+            tc = time.time()
+            o.kubo_moments(np.array([[1]], np.int32), np.ones((1, 1), np.complex128), c_ll, a, b, z["v_a"], z["v_b"], z.get("vo_a") if args.hoh else None, z.get("vo_b") if args.hoh else None)
+            tc = time.time() - tc
+            flop_c = FLOP_PER_BLOCK_MULT * acc["block_multiplies"] / args.steps / max(acc["hop_launches"] / args.steps, 1) * (3 * c_ll - 1) * (2 if args.hoh else 1) + 8.0 * (c_ll * 18.0) ** 2 * kk * 18.0
+            out["cpu_baseline"] = {"value": flop_c / tc * 1e-9, "unit": "GFLOP/s", "cores": oracle.lib().orc_num_threads(), "cpu_quota": cpu_quota(), "host_cpus": os.cpu_count(), "kind": "port", "seconds": tc,
+                                   "sample": "the same %d-atom lattice and operators at cond_ll=%d (%.1f GFLOP), C restatement oracle/rsrec_oracle.c (OpenMP)" % (kk, c_ll, flop_c * 1e-9)}
+    print(json.dumps(out), flush=True)
+    rec.close()
 
 
 def cpu_quota():
@@ -292,6 +396,8 @@ def profiled_traffic(workload_key, kernel):
 
 def main():
     args = parse_args()
+    if args.workload == "kubo":
+        return main_kubo(args)
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         launch_ranks(args)                      # never returns

@@ -46,6 +46,7 @@ module recursion_gpu_mod
       procedure :: zsqr => gpu_zsqr
       procedure :: get_terminf => gpu_get_terminf
       procedure :: compute_moments_stochastic => gpu_compute_moments_stochastic
+      procedure :: chebyshev_orbital_mod => gpu_chebyshev_orbital_mod
       procedure :: ham_vec_matmul => gpu_ham_vec_matmul
       procedure :: ham_hoh_vec_matmul => gpu_ham_hoh_vec_matmul
       procedure :: velo_vec_matmul => gpu_velo_vec_matmul
@@ -522,6 +523,72 @@ contains
    end subroutine gpu_compute_moments_stochastic
 
    !---------------------------------------------------------------------------
+   !> Orbital moment from position-operator Chebyshev moments (replaces recursion.f90:2834-3049).  The reference loops over all kk
+   !> atoms as seeds and sends every whole-lattice product through `ham_vec_matmul` on host arrays; here the seeds are chains of ONE
+   !> library call (rsrec_orbital_moments: all vectors resident on the device, the moment sums reduced there).  What follows the
+   !> moments -- the 1/kk average, the Jackson kernel, the energy sum, trace and integral written to unit 50 (:3006-3047) -- is the
+   !> reference's, restated.  Not reproduced: the per-seed diagnostic prints (:2909, :2972), and the reference's accumulation onto a
+   !> never-zeroed mu_n_orb (:2907 is commented out) -- the sum starts from zero here.
+   !---------------------------------------------------------------------------
+   subroutine gpu_chebyshev_orbital_mod(this)
+      use math_mod, only: jackson_kernel, rtrace, simpson_f, i_unit, pi
+      class(recursion_gpu), intent(inout) :: this
+      integer :: i, l, m, ie, nv, ll, k
+      integer(c_int) :: rc
+      integer(c_int), allocatable, target :: seeds(:)
+      real(rp), allocatable, target :: cr(:, :)
+      complex(rp), allocatable, target :: mu_n_orb(:, :, :)
+      complex(rp), dimension(18, 18, this%en%channels_ldos + 10) :: g0
+      real(rp), dimension(this%control%lld) :: kernel
+      real(rp), dimension(this%en%channels_ldos + 10) :: wscale, lzi
+      complex(rp) :: exp_factor
+      real(rp) :: a, b, lz
+
+      ll = this%control%lld
+      nv = this%en%channels_ldos + 10
+      a = (this%en%energy_max - this%en%energy_min)/(2 - 0.3)      ! :2869-2870 (default-REAL literals, as there)
+      b = (this%en%energy_max + this%en%energy_min)/2
+      wscale(:) = (this%en%ene(:) - b)/a
+      call jackson_kernel(ll, kernel)
+      call sync_device(this, .true.)
+      g_block_resident = 0
+      allocate (seeds(this%lattice%kk), cr(3, this%lattice%kk), mu_n_orb(18, 18, ll))
+      do k = 1, this%lattice%kk
+         seeds(k) = int(k, c_int)
+      end do
+      cr = this%lattice%cr(1:3, 1:this%lattice%kk)
+      call g_timer%start('chebyshev-orbital-gpu')
+      rc = rsrec_orbital_moments(g_handle, int(this%lattice%kk, c_int), c_loc(seeds), int(ll, c_int), real(a, c_double), real(b, c_double), &
+                                 c_loc(cr), real(this%lattice%alat, c_double), c_loc(mu_n_orb), c_null_ptr)
+      call g_timer%stop('chebyshev-orbital-gpu')
+      call check(rc, 'rsrec_orbital_moments')
+      this%izero(:) = 1
+
+      mu_n_orb(:, :, :) = mu_n_orb(:, :, :)/real(this%lattice%kk)   ! :3006
+      do l = 1, 18
+         do m = 1, 18
+            mu_n_orb(l, m, :) = mu_n_orb(l, m, :)*kernel(:)
+         end do
+      end do
+      mu_n_orb(:, :, 2:size(kernel)) = mu_n_orb(:, :, 2:size(kernel))*2.0_rp
+      g0(:, :, :) = (0.0d0, 0.0d0)
+      do ie = 1, nv                                                 ! :3019-3035
+         do i = 1, size(kernel)
+            exp_factor = -i_unit*exp(-i_unit*(i - 1)*acos(wscale(ie)))
+            g0(:, :, ie) = g0(:, :, ie) + mu_n_orb(:, :, i)*aimag(exp_factor)
+         end do
+         g0(:, :, ie) = g0(:, :, ie)/((sqrt((a**2) - ((this%en%ene(ie) - b)**2))))
+      end do
+      do ie = 1, nv
+         lzi(ie) = rtrace(g0(:, :, ie))
+      end do
+      do ie = 1, nv                                                 ! :3043-3046
+         call simpson_f(lz, this%en%ene, this%en%ene(ie), this%en%nv1, lzi, .true., .false., 0.0d0)
+         write (50, '(3es16.6)') this%en%ene(ie) - this%en%fermi, -(lz/pi), -(1/pi)*lzi(ie)
+      end do
+   end subroutine gpu_chebyshev_orbital_mod
+
+   !---------------------------------------------------------------------------
    !> Whole-vector products on caller arrays (replace recursion.f90:913, :785, :587, :656).  With these overridden, the inherited
    !> chebyshev_orbital_mod (:2834) runs its H|psi> on the GPU.  The region flags are left "all active" for the caller's
    !> `izero = idum` bookkeeping (blocks outside the reference's region are exact zeros).
@@ -559,7 +626,7 @@ contains
       complex(rp), dimension(:, :, :), intent(in) :: psi_in
       complex(rp), dimension(:, :, :), intent(out) :: psi_out
       real(rp), intent(in) :: a, b
-      call gpu_apply(this, 0, psi_in=psi_in, psi_out=psi_out, a=a, b=b)
+      call gpu_apply(this, 2, psi_in=psi_in, psi_out=psi_out, a=a, b=b)     ! 2: the plain operator ee + l.s also when hoh is set (:913-977)
    end subroutine gpu_ham_vec_matmul
 
    subroutine gpu_ham_hoh_vec_matmul(this, psi_in, psi_out, a, b)

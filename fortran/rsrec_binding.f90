@@ -193,6 +193,15 @@ module rsrec_binding
          integer(c_int), intent(out) :: start_atom, end_atom
       end subroutine
 
+      function rsrec_orbital_moments(handle, nseeds, seed_atoms, lld, a, b, cr, alat, mu_orb, mu_seed) bind(C, name='rsrec_orbital_moments') result(rc)
+         import :: c_int, c_ptr, c_double
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nseeds, lld
+         real(c_double), value :: a, b, alat
+         type(c_ptr), value :: seed_atoms, cr, mu_orb, mu_seed
+         integer(c_int) :: rc
+      end function
+
       function rsrec_pack_moments(handle, site_offset, nsites_total, mu_img) bind(C, name='rsrec_pack_moments') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

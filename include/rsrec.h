@@ -200,6 +200,17 @@ void rsrec_site_partition(int rank, int nprocs, int nsites, int *start_atom, int
 /* Last error text of this handle (NUL-terminated, truncated to n). */
 int rsrec_last_error(rsrec_t *h, char *buf, size_t n);
 
+/* chebyshev_orbital_mod (recursion.f90:2834-3049; called at calculation.f90:1256), the moment part (:2893-3013), with the seeds advanced
+ * together as chains and every vector resident on the device.  For seed atom s:  psiref = 1 on s;
+ * left = i (Y H~ X - X H~ Y) psiref  with X, Y = alat cr(1,:), alat cr(2,:) and H~ = ham_vec_matmul (the plain operator also when hoh is
+ * set);  v_1 = psiref, v_2 = H~' v_1, v_n = 2 H~' v_{n-1} - v_{n-2}  (H~' = ham_hoh_vec_matmul with hoh);  mu(:,:,n) = sum_k left_k^H v_n,k.
+ *   cr      : lattice%cr(3,kk), units of alat;   a, b : scale and shift of H~ = (H - b)/a  (:2869-2870)
+ *   mu_orb  : complex (18,18,lld): the SUM over the seeds of the call in seed order (the reference loops over all kk atoms and divides
+ *             by kk afterwards, :3006; its own accumulator is never zeroed, :2907 -- here the sum starts from zero)
+ *   mu_seed : optional complex (18,18,lld,nseeds): the contribution of every seed */
+int rsrec_orbital_moments(rsrec_t *h, int nseeds, const int32_t *seed_atoms, int lld, double a, double b, const double *cr, double alat,
+                          double *mu_orb, double *mu_seed);
+
 /* The Chebyshev counterpart of rsrec_pack_diag: the moments mu_n(18,18,2 lld + 2,site) of the last rsrec_chebyshev call, as they lie on
  * the device, inside a zero image over all sites (shape (18,18,2 lld + 2,nsites_total) complex; device or host memory) -- the buffer a
  * sum all-reduce turns into the all-gather of recursion.f90:1790-1793 (commented-out MPI_Allgather of the coefficients). */

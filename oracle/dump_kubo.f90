@@ -26,9 +26,10 @@ program dump_kubo
    type(hamiltonian), target :: hamiltonian_obj
    type(recursion), target :: recursion_obj
    type(mix), target :: mix_obj
-   integer :: i, u, hoh_i, nslots
+   integer :: i, u, hoh_i, nslots, elen, estat
    integer(8) :: t0, t1, rate
    real(rp) :: a, b
+   character(len=8) :: envv
 
    rank = 0
    numprocs = 1
@@ -55,6 +56,38 @@ program dump_kubo
    call hamiltonian_obj%build_bulkham()
    recursion_obj = recursion(hamiltonian_obj, energy_obj)
 
+   ! RSREC_DUMP_ORBITAL=1: the other whole-vector routine of this set-up, chebyshev_orbital_mod (recursion.f90:2834-3049, called at
+   ! calculation.f90:1256 after exactly the steps above).  Its only outputs are unit 50 (energy, integrated and energy-resolved orbital
+   ! moment, 3es16.6) and stdout; `orbital.bin` carries the inputs.
+   call get_environment_variable('RSREC_DUMP_ORBITAL', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) then
+      call system_clock(t0, rate)
+      call recursion_obj%chebyshev_orbital_mod()
+      call system_clock(t1)
+      write (*, '(a,f12.6,a)') 'dump_kubo: chebyshev_orbital_mod wall time ', real(t1 - t0, rp)/real(rate, rp), ' s'
+      flush (50)
+      a = (energy_obj%energy_max - energy_obj%energy_min)/(2 - 0.3)
+      b = (energy_obj%energy_max + energy_obj%energy_min)/2
+      nslots = size(hamiltonian_obj%ee, 3)
+      hoh_i = 0
+      if (hamiltonian_obj%hoh) hoh_i = 1
+      open (newunit=u, file='orbital.bin', access='stream', form='unformatted', status='replace')
+      write (u) int(z'4f52424d'), 1
+      write (u) lattice_obj%kk, size(lattice_obj%nn, 2), lattice_obj%nmax, lattice_obj%ntype, control_obj%lld, control_obj%nsp, hoh_i, nslots, &
+         energy_obj%channels_ldos + 10, energy_obj%nv1
+      write (u) a, b, lattice_obj%alat, energy_obj%fermi
+      write (u) lattice_obj%iz(1:lattice_obj%kk)
+      write (u) lattice_obj%nn
+      write (u) hamiltonian_obj%ee
+      write (u) hamiltonian_obj%lsham
+      write (u) hamiltonian_obj%eeo
+      write (u) hamiltonian_obj%enim
+      write (u) lattice_obj%cr(1:3, 1:lattice_obj%kk)
+      write (u) energy_obj%ene(1:energy_obj%channels_ldos + 10)
+      close (u)
+      stop
+   end if
+
    call system_clock(t0, rate)
    call recursion_obj%compute_moments_stochastic()
    call system_clock(t1)
@@ -66,7 +99,7 @@ program dump_kubo
    hoh_i = 0
    if (hamiltonian_obj%hoh) hoh_i = 1
    open (newunit=u, file='kubo.bin', access='stream', form='unformatted', status='replace')
-   write (u) int(z'4b55424f'), 1
+   write (u) int(z'4b55424f'), 2
    write (u) lattice_obj%kk, size(lattice_obj%nn, 2), lattice_obj%nmax, lattice_obj%ntype, control_obj%cond_ll, control_obj%nsp, hoh_i, nslots, &
       size(recursion_obj%mu_nm_stochastic, 5)
    write (u) a, b
@@ -82,5 +115,6 @@ program dump_kubo
    write (u) hamiltonian_obj%vo_a
    write (u) hamiltonian_obj%vo_b
    write (u) recursion_obj%mu_nm_stochastic
+   write (u) lattice_obj%cr(1:3, 1:lattice_obj%kk), lattice_obj%alat          ! version 2: positions (units of alat) and alat
    close (u)
 end program dump_kubo

@@ -309,6 +309,12 @@ def run_kubo_case(name):
                              ("v_a", (18, 18, nslots, ntype)), ("v_b", (18, 18, nslots, ntype)), ("vo_a", (18, 18, nslots, ntype)), ("vo_b", (18, 18, nslots, ntype))):
                 d[k] = rd(f, np.complex128, shape)
             d["mu_nm"] = rd(f, np.complex128, (18, 18, cond_ll, cond_ll, nvec))
+            if version >= 2:            # positions: only to name the displacement vector of every neighbour slot (supercell generator)
+                d["cr"] = rd(f, np.float64, (3, kk))
+                alat = struct.unpack("<d", f.read(8))[0]
+                d["slot_vec"] = slot_vectors(d)          # from an interior atom of the (free) cluster
+                d.pop("cr")
+                d["alat"] = alat
             assert f.read(1) == b""
         if not hoh:
             for k in ("eeo", "enim", "vo_a", "vo_b"):
@@ -319,6 +325,71 @@ def run_kubo_case(name):
         wall = [l for l in r.stdout.splitlines() if "wall time" in l]
         print("%-24s kk=%d nslots=%d cond_ll=%d hoh=%d |mu|max=%.3e -> %.1f KB  (%s)" % (name, kk, nslots, cond_ll, hoh, np.abs(d["mu_nm"]).max(),
                                                                                    os.path.getsize(path) / 1024, wall[-1].strip() if wall else ""))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
+ORBITAL_CASES = {
+    # chebyshev_orbital_mod loops over ALL atoms as seeds (kk x lld whole-lattice products): a small free fcc Pt cluster
+    "fccPt_orbital": ("tests/postproc/cases/conductivity/fccPt", {"lattice": {"n1": 5, "n2": 5, "n3": 5}, "control": {"lld": 8}, "hamiltonian": {"hoh": ".false."}}),
+    "fccPt_orbital_hoh": ("tests/postproc/cases/conductivity/fccPt", {"lattice": {"n1": 5, "n2": 5, "n3": 5}, "control": {"lld": 8}, "hamiltonian": {"hoh": ".true."}}),
+}
+
+
+def run_orbital_case(name):
+    """<name>.npz: inputs of recursion%chebyshev_orbital_mod (recursion.f90:2834) and what the compiled reference writes: unit 50
+    (`fort.50`: E - E_F, -Lz(E)/pi integrated, -lz(E)/pi energy-resolved; 3es16.6 = 7 significant digits) and, per seed atom, the
+    list-directed sums it prints (sum(left_vec), sum(psiref), sum(left_vec1), sum(left_vec2): full precision).  The moments
+    themselves are a local variable of the routine and never leave it."""
+    import struct
+    case_dir, patch = ORBITAL_CASES[name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_orb_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        p = os.path.join(scratch, "input.nml")
+        txt = open(p).read()
+        head, sep, tail = txt.rpartition("&hamiltonian")          # (see run_kubo_case: two &hamiltonian groups, undeclared keys)
+        if "&hamiltonian" in head:
+            txt = head + tail[tail.index("/") + 1:]
+        txt = "\n".join(l for l in txt.splitlines() if not re.match(r"\s*(js_alpha|cond_type)\s*=", l)) + "\n"
+        txt = patch_namelist(txt, patch)
+        open(p, "w").write(txt)
+        r = run_with_unlimited_stack([os.path.join(HERE, "_ref", "dump_kubo.x")], cwd=scratch, env={"OMP_NUM_THREADS": "8", "RSREC_DUMP_ORBITAL": "1"})
+        if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "orbital.bin")):
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_kubo (orbital) failed for " + name)
+        with open(os.path.join(scratch, "orbital.bin"), "rb") as f:
+            magic, version = struct.unpack("<ii", f.read(8))
+            assert magic == 0x4f52424d
+            kk, nncols, nmax, ntype, lld, nsp, hoh, nslots, nv, nv1 = struct.unpack("<10i", f.read(40))
+            a, b, alat, fermi = struct.unpack("<4d", f.read(32))
+            rd = fio._rd
+            d = dict(kk=kk, nmax=nmax, ntype=ntype, lld=lld, nsp=nsp, hoh=hoh, nslots=nslots, acheb=a, bcheb=b, alat=alat, fermi=fermi, nv1=nv1)
+            d["iz"] = rd(f, np.int32, (kk,)); d["nn"] = rd(f, np.int32, (kk, nncols))
+            for k, shape in (("ee", (18, 18, nslots, ntype)), ("lsham", (18, 18, ntype)), ("eeo", (18, 18, nslots, ntype)), ("enim", (18, 18, ntype))):
+                d[k] = rd(f, np.complex128, shape)
+            d["cr"] = rd(f, np.float64, (3, kk))
+            d["ene"] = rd(f, np.float64, (nv,))
+            assert f.read(1) == b""
+        if not hoh:
+            d.pop("eeo"); d.pop("enim")
+        rows = [[float(v) for v in l.split()] for l in open(os.path.join(scratch, "fort.50")).read().splitlines() if l.strip()]
+        d["fort50"] = np.array(rows)
+        assert d["fort50"].shape == (nv, 3)
+        # per-seed sums: list-directed complex numbers "(re,im)", four per seed, possibly wrapped over lines
+        flat = re.sub(r"\s+", "", r.stdout)
+        c = re.findall(r"\(([-+0-9.eEdD]+),([-+0-9.eEdD]+)\)", flat)
+        if len(c) == 4 * kk:
+            d["seed_sums"] = np.array([complex(float(x.replace("D", "E")), float(y.replace("D", "E"))) for x, y in c]).reshape(kk, 4)
+        d["source_case"] = np.array(case_dir); d["namelist_patch"] = np.array(repr(patch))
+        path = os.path.join(GOLD, name + ".npz")
+        np.savez_compressed(path, **d)
+        wall = [l for l in r.stdout.splitlines() if "wall time" in l]
+        print("%-24s kk=%d lld=%d hoh=%d nv=%d seed_sums=%s |lz|max=%.3e -> %.1f KB  (%s)" % (name, kk, lld, hoh, nv, "seed_sums" in d, np.abs(d["fort50"][:, 2]).max(),
+                                                                                      os.path.getsize(path) / 1024, wall[-1].strip() if wall else ""))
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 
@@ -345,11 +416,13 @@ def spread_case(name, threads=(1, 2, 8)):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES)
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES)
                             + ["sc_4x4x8_block_spread", "sc_4x4x8_block_hoh_spread"])
     for n in want:
         if n in KUBO_CASES:
             run_kubo_case(n)
+        elif n in ORBITAL_CASES:
+            run_orbital_case(n)
         elif n.endswith("_spread"):
             spread_case(n[:-len("_spread")])
         elif n.endswith("_green"):

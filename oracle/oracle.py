@@ -120,6 +120,23 @@ class Oracle:
         assert rc == 0
         return mu
 
+    def orbital_moments(self, seeds, lld, a, b, cr, alat, per_seed=False):
+        """chebyshev_orbital_mod (recursion.f90:2834), moment part: sum over `seeds` of sum_k left_k^H T_{n-1}(H~) r  -> (18,18,lld)
+        [per_seed: and the per-seed contributions (18,18,lld,nseeds) and the sums (3,nseeds) of left_vec, left_vec1, left_vec2 the reference prints]."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        crf = _f(cr, np.float64)
+        mu = np.zeros((18, 18, lld), np.complex128, order="F")
+        ms = np.zeros((18, 18, lld, len(seeds)), np.complex128, order="F") if per_seed else None
+        sums = np.zeros((3, len(seeds)), np.complex128, order="F") if per_seed else None
+        L = lib()
+        L.orc_orbital_moments.restype = C.c_int
+        L.orc_orbital_moments.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = L.orc_orbital_moments(C.byref(self.P), len(seeds), seeds.ctypes.data_as(C.c_void_p), int(lld), float(a), float(b), crf.ctypes.data_as(C.c_void_p),
+                                   float(alat), mu.ctypes.data_as(C.c_void_p), None if ms is None else ms.ctypes.data_as(C.c_void_p),
+                                   None if sums is None else sums.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return (mu, ms, sums) if per_seed else mu
+
     def scalar_lanczos(self, seeds, lld, llmax=None):
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         n = len(seeds)

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "rsrec_block_lanczos_seeded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_block_lanczos_local_axis": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rsrec_pack_diag": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rsrec_orbital_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     "rsrec_pack_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rsrec_comm_unique_id": (C.c_int, [C.c_char_p]),
     "rsrec_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),

@@ -48,4 +48,32 @@ __global__ __launch_bounds__(384) void k_block_transpose(int kk, const double2* 
     }
 }
 
+// ---- chebyshev_orbital_mod (recursion.f90:2834-3049) ------------------------------------------------------------------------------
+// left_k = i (Y_k alat (x_s alat t_k) - X_k alat (y_s alat t_k)),  t = H~ psiref of the chain's seed atom s  (:2944-2971: psiref lives on
+// atom s alone, so X|r> = alat x_s |r> and the two whole-lattice products of the reference are the same vector t times a number).
+// One workgroup column per chain (grid.y); element-wise on the 324 complex entries of every atom block: layout-blind.
+__global__ void k_orb_left(int kk, size_t vstride, const int* __restrict__ seed /*[chain]*/, const double* __restrict__ cr /*(3,kk)*/, double alat,
+                           double2* __restrict__ vec /*in: t, out: left*/) {
+    const int chain = blockIdx.y;
+    const int s = seed[chain];
+    const double xs = cr[3 * (size_t)s] * alat, ys = cr[3 * (size_t)s + 1] * alat;
+    double2* v = vec + (size_t)chain * (vstride / 2);
+    const size_t n = (size_t)kk * BLK;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = e / BLK;
+        const double xk = cr[3 * k] * alat, yk = cr[3 * k + 1] * alat;
+        const double2 t = v[e];
+        const double l1r = yk * (xs * t.x), l1i = yk * (xs * t.y), l2r = xk * (ys * t.x), l2i = xk * (ys * t.y);
+        v[e] = make_double2(-(l1i - l2i), l1r - l2r);                  // i (l1 - l2)
+    }
+}
+
+// 36x36 Gram partials of k_mfma_adot -> the 18x18 complex matrix sum_rows X^H Y of every chain, as it is (no coefficient sandwich)
+__global__ __launch_bounds__(1024) void k_reduce_gram_out(const double* __restrict__ partial, int nblk, double2* out, size_t stride, int ci) {
+    __shared__ double lds[1296];
+    const int chain = blockIdx.x;
+    const double2 c = reduce_gram(partial + (size_t)chain * nblk * 1296, nblk, lds, ci);
+    if (threadIdx.x < BLK) out[chain * stride + threadIdx.x] = c;
+}
+
 }  // namespace rsrec

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rsrec.h"
@@ -91,6 +92,7 @@ struct rsrec_handle {
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
+    Spmm5Operator orb_plain;                // h as ham_vec_matmul applies it when hoh is set (rsrec_orbital_moments, rsrec_apply_operator vel = 2)
     void* rocblas_lib = nullptr; void* rocblas_handle = nullptr;
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
@@ -101,6 +103,8 @@ struct rsrec_handle {
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
+    long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
+    int n_kubo_left_chunks = 0;
     long opt_orth3 = 1;          // k_mfma_orth3: 1 one 512-register wave per SIMD (tables in registers), 2 two waves per SIMD (tables in LDS)
     long opt_graph = 1;          // level loop of small batches as one HIP graph: 0 never, 1 calls of up to 8 chains, 2 every single-batch call
     // The captured level loop of the last small-batch block-Lanczos call (every SCF iteration repeats it with the same lattice, seeds,
@@ -348,7 +352,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->s4_op.release();
     h->s5_op.release();
-    h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release(); h->s5_la.release(); h->d_la_extra.release();
+    h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release(); h->orb_plain.release(); h->s5_la.release(); h->d_la_extra.release();
     if (h->rocblas_handle && g_rocblas_destroy) g_rocblas_destroy(h->rocblas_handle);
     if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
@@ -386,6 +390,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "graph")) h->opt_graph = value;
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
+    else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -2067,12 +2072,35 @@ struct KuboCtx {
     dim3 grid;
     const int* iz;
     double *hps, *p1, *p2;      // temporaries of the two-pass products
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* spmm_ev = nullptr;   // timing of every SpMM launch (rsrec_kubo_moments)
+    std::vector<std::tuple<const Spmm5Operator*, int, double>>* req = nullptr;
 };
+
+// flops one whole-lattice product with operator (op, set) requires by its block structure (see required_hop_flops)
+double kubo_required_flops(const rsrec_t* h, const Spmm5Operator& op, int set) {
+    double f = 0.0;
+    const int ns = h->nslots;
+    for (int i = 0; i < h->kk; ++i) {
+        const int tau = i < h->nmax ? i : h->nmax + h->iz0[i];
+        for (int s2 = 0; s2 < ns; ++s2)
+            if (h->nbr[(size_t)i * ns + s2] >= 0) f += op.required_flops(set, tau, s2);
+        f += op.required_flops(set, tau, ns);               // the extra on-site slot of two-input passes (0 if the class has none)
+    }
+    return f;
+}
 
 void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double* in, double* out, const double* in2, S5Epilogue epi = S5Epilogue()) {
     rsrec_t* h = K.h;
+    hipEvent_t e0 = K.spmm_ev ? next_event(h) : nullptr;
     if (in2) launch_s5<true>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, in2, nullptr, 0, epi);
     else launch_s5<false>(h, K.grid, K.SD, K.CV.order, K.CV.cum, K.iz, op, set, in, out, nullptr, nullptr, 0, epi);
+    if (K.spmm_ev) {
+        K.spmm_ev->emplace_back(e0, next_event(h));
+        double f = -1.0;                                  // required flops of (op, set): computed once per call
+        for (auto& e : *K.req) if (std::get<0>(e) == &op && std::get<1>(e) == set) f = std::get<2>(e);
+        if (f < 0.0) { f = kubo_required_flops(h, op, set); K.req->emplace_back(&op, set, f); }
+        h->n_req_flop += f;
+    }
 }
 // out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift), or with an epilogue the whole Chebyshev
 // step  out = (H in - b in)/a  [* 2 - old]  (their scale-and-shift :968-970 and the caller's recurrence :1132-1136) in the same kernel
@@ -2119,19 +2147,26 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
     const size_t ld = (size_t)kk * NB;                       // rows of the moment matrices: (atom, orbital row)
     const int nchunk = std::min(cond_ll, 64);                // right vectors per GEMM
-    // device memory: 11 work vectors, the left matrix (cond_ll vectors), one chunk of right vectors, one chunk of moments
-    const size_t need = 11 * velems * 8 + ((size_t)cond_ll + nchunk) * ld * NB * 16 + (size_t)cond_ll * NB * nchunk * NB * 16;
+    // device memory: 11 work vectors, a chunk of the left matrix (lchunk vectors), one chunk of right vectors, one chunk of moments.
+    // The left matrix is held in chunks of `lchunk` vectors (all of them if they fit: cond_ll x kk x 5184 B is 21 GB for cond_ll = 500
+    // on 8 000 atoms, 252 GB on 10^5): each chunk continues the left recurrence where the previous one stopped and is contracted
+    // with ALL right vectors, so the right recurrence (2 of the 3 SpMMs per moment order) is repeated once per chunk.
     size_t free_b = 0, total_b = 0;
     HIPCK(h, hipMemGetInfo(&free_b, &total_b));
     size_t reusable = 0;
     for (int v = 0; v < 6; ++v) reusable += h->d_vec[v].bytes;
-    if ((double)need > 0.9 * (double)(free_b + reusable))
-        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for cond_ll = %d on %d atoms, %.1f GB free", need * 1e-9, cond_ll, kk, free_b * 1e-9);
+    const double budget = 0.9 * (double)(free_b + reusable);
+    auto need_for = [&](int lc) { return 11.0 * velems * 8 + ((double)lc + nchunk) * ld * NB * 16 + (double)lc * NB * nchunk * NB * 16; };
+    int lchunk = cond_ll;
+    if (h->opt_kubo_lchunk > 0) lchunk = (int)std::min<long>(cond_ll, h->opt_kubo_lchunk);
+    while (lchunk > 1 && need_for(lchunk) > budget) lchunk = (lchunk + 1) / 2;
+    if (need_for(lchunk) > budget)
+        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for one left vector at a time on %d atoms, %.1f GB free", need_for(1) * 1e-9, kk, free_b * 1e-9);
     for (int v = 0; v < 6; ++v) h->d_vec[v].release();
     DevBuf work, Lm, Rm, Mu;
     auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Mu.release(); };
-    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)cond_ll * ld * NB * 16) != hipSuccess ||
-        Rm.reserve((size_t)nchunk * ld * NB * 16) != hipSuccess || Mu.reserve((size_t)cond_ll * NB * nchunk * NB * 16) != hipSuccess) {
+    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)lchunk * ld * NB * 16) != hipSuccess ||
+        Rm.reserve((size_t)nchunk * ld * NB * 16) != hipSuccess || Mu.reserve((size_t)lchunk * NB * nchunk * NB * 16) != hipSuccess) {
         cleanup();
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: out of device memory");
     }
@@ -2139,6 +2174,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     double* V[11];
     for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * velems;
     double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3], *right = V[5];
+    double *l0 = V[4], *l1 = V[9], *l2 = V[10];                                 // state of the left recurrence (survives from chunk to chunk)
     HIPCK(h, h->d_seed.reserve((size_t)nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)nseed * sizeof(double2)));
     // region list: all atoms (every launch of this path runs over the whole lattice)
@@ -2155,9 +2191,13 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     K.grid = s5_grid(h, dim3(256, 1), 0);
     K.iz = h->d_iz.as<int>();
     K.hps = V[6]; K.p1 = V[7]; K.p2 = V[8];
-    const int m_rows = cond_ll * NB;
-    std::vector<double> mu_chunk((size_t)m_rows * nchunk * NB * 2);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spmm_ev, gemm_ev;
+    K.spmm_ev = &spmm_ev;
+    std::vector<std::tuple<const Spmm5Operator*, int, double>> req_tab;
+    K.req = &req_tab;
+    std::vector<double> mu_chunk((size_t)lchunk * NB * nchunk * NB * 2);
     hipEvent_t e_begin = next_event(h);
+    int n_left_chunks = 0;
     for (int iv = 0; iv < nvec; ++iv) {
         // r_i: psiref(l,l,seed(k)) = coef(k); seed atom 0 = unused entry
         std::vector<int> s0; std::vector<double> c0;
@@ -2171,53 +2211,59 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         XFER(xfer_h2d(h, h->d_seedcoef.p, c0.data(), c0.size() * 8));
         HIPCK(h, hipMemsetAsync(psiref, 0, nd * 8, h->stream));
         k_seed<LayoutCI><<<1, 64, 0, h->stream>>>(psiref, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), (int)s0.size());
-        // left vectors  T_{m-1}(H~) r  ->  columns of L (recursion.f90:1120-1142)
-        double *x0 = w0, *x1 = w1, *x2 = w2;
+        double *x0 = l0, *x1 = l1, *x2 = l2;
         HIPCK(h, hipMemcpyAsync(x1, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
-        for (int m = 0; m < cond_ll; ++m) {
-            if (m == 1) {
-                std::swap(x0, x1);                                        // w0 = w1
-                kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
-            } else if (m > 1) {
-                kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
-                double* o = x0; x0 = x1; x1 = x2; x2 = o;                 // w0 = w1, w1 = w2
-            }
-            k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(x1), Lm.as<double2>(), ld, m * NB);
-        }
-        // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), contracted with all left vectors chunk by chunk
-        x0 = w0; x1 = w1; x2 = w2;
-        kubo_apply_v(K, h->kubo_op[1], psiref, x1);                       // v1 = v0 = v_b r
-        for (int n = 0; n < cond_ll; ++n) {
-            if (n == 1) {
-                std::swap(x0, x1);
-                kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
-            } else if (n > 1) {
-                kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
-                double* o = x0; x0 = x1; x1 = x2; x2 = o;
-            }
-            kubo_apply_v(K, h->kubo_op[0], x1, right);
-            const int nl = n % nchunk;
-            k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(right), Rm.as<double2>(), ld, nl * NB);
-            if (nl == nchunk - 1 || n == cond_ll - 1) {
-                const int ncols = (nl + 1) * NB;
-                const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
-                HIPCK(h, hipGetLastError());
-                HIPCK(h, hipMemsetAsync(Mu.p, 0, (size_t)m_rows * ncols * 16, h->stream));     // (beta = 0 below; the buffer is fresh device memory)
-                // Mu[(m,c), (n,c')] = sum_{k,r} conj(L[(k,r),(m,c)]) R[(k,r),(n,c')]    (zgemm 'C','N'; rocblas_operation codes 113 / 111)
-                if (g_rocblas.zgemm(h->rocblas_handle, 113, 111, m_rows, ncols, (int)ld, one, Lm.p, (int)ld, Rm.p, (int)ld, zero, Mu.p, m_rows) != 0) {
-                    cleanup();
-                    return fail(h, RSREC_ERR_DEVICE, "rocblas_zgemm failed");
+        for (int m0 = 0; m0 < cond_ll; m0 += lchunk) {
+            const int ml = std::min(lchunk, cond_ll - m0), m_rows = ml * NB;
+            ++n_left_chunks;
+            // left vectors  T_{m-1}(H~) r,  m = m0 .. m0 + ml - 1  ->  columns of L (recursion.f90:1120-1142)
+            for (int m = m0; m < m0 + ml; ++m) {
+                if (m == 1) {
+                    std::swap(x0, x1);                                        // w0 = w1
+                    kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
+                } else if (m > 1) {
+                    kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
+                    double* o = x0; x0 = x1; x1 = x2; x2 = o;                 // w0 = w1, w1 = w2
                 }
-                XFER(xfer_d2h(h, mu_chunk.data(), Mu.p, (size_t)m_rows * ncols * 16));
-                const int n0 = n - nl;
-                for (int q = 0; q <= nl; ++q)
-                    for (int cp = 0; cp < NB; ++cp)
-                        for (int m = 0; m < cond_ll; ++m)
-                            for (int c = 0; c < NB; ++c) {
-                                const size_t src = 2 * ((size_t)(m * NB + c) + (size_t)m_rows * (q * NB + cp));
-                                const size_t dst = 2 * ((size_t)c + NB * ((size_t)cp + NB * ((size_t)(n0 + q) + cond_ll * ((size_t)m + (size_t)cond_ll * iv))));
-                                mu_nm[dst] = mu_chunk[src]; mu_nm[dst + 1] = mu_chunk[src + 1];
-                            }
+                k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(x1), Lm.as<double2>(), ld, (m - m0) * NB);
+            }
+            // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), contracted with the left vectors of this chunk, 64 at a time
+            double *y0 = w0, *y1 = w1, *y2 = w2;
+            kubo_apply_v(K, h->kubo_op[1], psiref, y1);                       // v1 = v0 = v_b r
+            for (int n = 0; n < cond_ll; ++n) {
+                if (n == 1) {
+                    std::swap(y0, y1);
+                    kubo_apply_h(K, y0, y1, cheb_epilogue(true, y0, nullptr, a, b));
+                } else if (n > 1) {
+                    kubo_apply_h(K, y1, y2, cheb_epilogue(false, y1, y0, a, b));
+                    double* o = y0; y0 = y1; y1 = y2; y2 = o;
+                }
+                kubo_apply_v(K, h->kubo_op[0], y1, right);
+                const int nl = n % nchunk;
+                k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(right), Rm.as<double2>(), ld, nl * NB);
+                if (nl == nchunk - 1 || n == cond_ll - 1) {
+                    const int ncols = (nl + 1) * NB;
+                    const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
+                    HIPCK(h, hipGetLastError());
+                    hipEvent_t g0 = next_event(h);
+                    HIPCK(h, hipMemsetAsync(Mu.p, 0, (size_t)m_rows * ncols * 16, h->stream));     // (beta = 0 below; the buffer is fresh device memory)
+                    // Mu[(m,c), (n,c')] = sum_{k,r} conj(L[(k,r),(m,c)]) R[(k,r),(n,c')]    (zgemm 'C','N'; rocblas_operation codes 113 / 111)
+                    if (g_rocblas.zgemm(h->rocblas_handle, 113, 111, m_rows, ncols, (int)ld, one, Lm.p, (int)ld, Rm.p, (int)ld, zero, Mu.p, m_rows) != 0) {
+                        cleanup();
+                        return fail(h, RSREC_ERR_DEVICE, "rocblas_zgemm failed");
+                    }
+                    gemm_ev.emplace_back(g0, next_event(h));
+                    XFER(xfer_d2h(h, mu_chunk.data(), Mu.p, (size_t)m_rows * ncols * 16));
+                    const int n0 = n - nl;
+                    for (int q = 0; q <= nl; ++q)
+                        for (int cp = 0; cp < NB; ++cp)
+                            for (int m = 0; m < ml; ++m)
+                                for (int c = 0; c < NB; ++c) {
+                                    const size_t src = 2 * ((size_t)(m * NB + c) + (size_t)m_rows * (q * NB + cp));
+                                    const size_t dst = 2 * ((size_t)c + NB * ((size_t)cp + NB * ((size_t)(n0 + q) + cond_ll * ((size_t)(m0 + m) + (size_t)cond_ll * iv))));
+                                    mu_nm[dst] = mu_chunk[src]; mu_nm[dst + 1] = mu_chunk[src + 1];
+                                }
+                }
             }
         }
     }
@@ -2225,8 +2271,149 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipGetLastError());
     h->t_total_ms = ev_ms(e_begin, e_end);
-    h->n_hop_launch = (double)nvec * (3.0 * cond_ll - 1) * (h->hoh ? 2 : 1);
+    for (auto& pr : spmm_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);          // the SpMM kernels (H and velocity products)
+    for (auto& pr : gemm_ev) h->t_rest_ms += ev_ms(pr.first, pr.second);         // "rest_ms" here: the moment GEMMs (rocBLAS zgemm)
+    h->n_hop_launch = (double)spmm_ev.size();
+    h->n_kubo_left_chunks = n_left_chunks;
+    // work in the reference's terms: every product is over the whole lattice -- one block multiply per (atom, present slot)
+    {
+        double fan = 0.0;
+        for (int i = 0; i < kk; ++i)
+            for (int s2 = 0; s2 < h->nslots; ++s2) if (h->nbr[(size_t)i * h->nslots + s2] >= 0) fan += 1.0;
+        h->n_block_mult = fan * (double)spmm_ev.size();
+        h->n_atom_steps = (double)kk * (double)spmm_ev.size();
+    }
     cleanup();
+    return RSREC_OK;
+}
+
+namespace {
+
+// h as ham_vec_matmul applies it (recursion.f90:913-977): per-type blocks ee (per-atom hall for the impurity region) with l.s added to
+// the on-site block -- whatever hamiltonian%hoh says.  Without hoh that is set 0 of s5_op; with hoh a table of its own.
+int build_plain_operator(rsrec_t* h) {
+    const int ntau = h->nmax + h->ntype, nfs = h->nslots + 1;
+    const size_t B = 2 * (size_t)BLK;
+    std::vector<const double*> blk((size_t)ntau * nfs, nullptr);
+    std::vector<double> onsite((size_t)ntau * B);
+    for (int tau = 0; tau < ntau; ++tau) {
+        const int ty = tau < h->nmax ? h->iz0[tau] : tau - h->nmax;
+        const double* base = tau < h->nmax ? h->host_hall.data() + B * (size_t)h->hslots * tau : h->host_ee.data() + B * (size_t)h->hslots * (tau - h->nmax);
+        for (size_t e = 0; e < B; ++e) onsite[(size_t)tau * B + e] = base[e] + h->host_lsham[B * ty + e];
+        blk[(size_t)tau * nfs] = onsite.data() + (size_t)tau * B;
+        for (int s = 1; s < h->nslots; ++s) blk[(size_t)tau * nfs + s] = base + B * s;
+    }
+    const char* msg = h->orb_plain.build_custom(h->nslots, ntau, 1, blk);
+    if (msg) return fail(h, RSREC_ERR_DEVICE, "plain operator table: %s", msg);
+    return RSREC_OK;
+}
+
+}  // namespace
+
+// chebyshev_orbital_mod (recursion.f90:2834-3049), the moment part (:2893-3013), device-resident: the seeds are chains advanced together.
+// For seed atom s:  psiref = 1 on s;  left = i (Y H~ X - X H~ Y) psiref  (X, Y = alat cr(1,:), alat cr(2,:); H~ = ham_vec_matmul, the
+// plain operator also when hoh is set);  v_1 = psiref, v_2 = H~' v_1, v_n = 2 H~' v_{n-1} - v_{n-2}  (H~' = ham_hoh_vec_matmul with hoh);
+// mu(:,:,n) = sum_k left_k^H v_n,k.  Every product runs over the whole lattice (the reference sets izero = 1, :2920).
+//   mu_orb  complex (18,18,lld): the SUM over the seeds of the call, added in seed order (the reference loops over all kk atoms and
+//           divides by kk afterwards, :3006);  mu_seed (optional) complex (18,18,lld,nseeds): every seed's contribution.
+extern "C" int rsrec_orbital_moments(rsrec_t* h, int nseeds, const int32_t* seed_atoms, int lld, double a, double b, const double* cr, double alat,
+                                     double* mu_orb, double* mu_seed) {
+    int rc = check_ready(h, "rsrec_orbital_moments");
+    if (rc) return rc;
+    if (nseeds < 0 || lld < 1 || a == 0.0 || !cr || !mu_orb || (nseeds > 0 && !seed_atoms)) return fail(h, RSREC_ERR_ARG, "rsrec_orbital_moments: bad argument");
+    for (int q = 0; q < nseeds; ++q)
+        if (seed_atoms[q] < 1 || seed_atoms[q] > h->kk) return fail(h, RSREC_ERR_ARG, "rsrec_orbital_moments: seed atom %d outside 1..%d", seed_atoms[q], h->kk);
+    if (!h->s5_built) return fail(h, RSREC_ERR_ARG, "rsrec_orbital_moments: lattice has too many neighbour slots for the SpMM kernel");
+    HIPCK(h, hipSetDevice(h->device));
+    reset_timing(h);
+    std::fill(mu_orb, mu_orb + 2 * (size_t)BLK * lld, 0.0);
+    if (nseeds == 0) return RSREC_OK;
+    const int kk = h->kk;
+    const bool hoh = h->hoh != 0;
+    if (hoh) { rc = build_plain_operator(h); if (rc) return rc; }
+    const Spmm5Operator& plain = hoh ? h->orb_plain : h->s5_op;
+    const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
+    const int nvec = hoh ? 5 : 4;                                  // left, v0, v1, v2 (+ h v of the two-pass product)
+    BatchPlan bp;
+    rc = plan_batch(h, nseeds, nvec, velems / 2, bp);
+    if (rc) return rc;
+    const int B = bp.batch;
+    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
+    const size_t gram_elems = (size_t)B * 256 * 1296;
+    HIPCK(h, h->d_partial.reserve(2 * gram_elems * sizeof(double)));
+    h->p2_slot = (size_t)B * 16 * 2 * 1296;
+    HIPCK(h, h->d_partial2.reserve(2 * h->p2_slot * sizeof(double)));
+    HIPCK(h, h->d_seed.reserve((size_t)B * 4));
+    HIPCK(h, h->d_seedcoef.reserve((size_t)B * sizeof(double2)));
+    HIPCK(h, h->d_scal.reserve((size_t)3 * kk * sizeof(double)));
+    HIPCK(h, h->d_zsqr.reserve((size_t)B * lld * BLK * sizeof(double2)));           // the chains' moments
+    XFER(xfer_h2d(h, h->d_scal.p, cr, (size_t)3 * kk * sizeof(double)));
+    std::vector<int> all(kk);
+    for (int i = 0; i < kk; ++i) all[i] = i;
+    int ostride = kk;
+    double dummy1 = 0, dummy2 = 0;
+    rc = upload_regions(h, all.data(), 1, kk, 1, 1, false, true, ostride, dummy1, dummy2);
+    if (rc) return rc;
+    double2* d_out = h->d_zsqr.as<double2>();
+    const size_t ostr = (size_t)lld * BLK;
+    std::vector<double> host_out;
+    hipEvent_t e_begin = next_event(h);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spmm_ev;
+    std::vector<std::tuple<const Spmm5Operator*, int, double>> req_tab;
+    for (int c0 = 0; c0 < nseeds; c0 += B) {
+        const int nb = std::min(B, nseeds - c0);
+        std::vector<int> s0(nb);
+        std::vector<double> one(2 * (size_t)nb, 0.0);
+        for (int q = 0; q < nb; ++q) { s0[q] = seed_atoms[c0 + q] - 1; one[2 * (size_t)q] = 1.0; }
+        XFER(xfer_h2d(h, h->d_seed.p, s0.data(), s0.size() * 4));
+        XFER(xfer_h2d(h, h->d_seedcoef.p, one.data(), one.size() * 8));
+        KuboCtx K;
+        K.h = h;
+        K.CV.order = h->cur_order; K.CV.cum = h->cur_cum; K.CV.obase = h->cur_cum + (size_t)h->cur_nrows * 1; K.CV.nlev = 1; K.CV.vstride = velems; K.CV.cpo = nb; K.CV.ostride = ostride;
+        K.SD = SpmmDims{kk, h->nslots, h->nmax, 1, nb, ostride, 0, velems, K.CV.obase, nb};
+        K.grid = s5_grid(h, dim3(256, nb), 0);
+        K.iz = h->d_iz.as<int>();
+        K.spmm_ev = &spmm_ev; K.req = &req_tab;
+        double* left = h->d_vec[0].as<double>();
+        double *v0 = h->d_vec[1].as<double>(), *v1 = h->d_vec[2].as<double>(), *v2 = h->d_vec[3].as<double>();
+        K.hps = hoh ? h->d_vec[4].as<double>() : nullptr; K.p1 = nullptr; K.p2 = nullptr;
+        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+        k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(v1, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), 1);     // v_1 = psiref
+        // t = H~ psiref with the plain operator, then the position factors
+        kubo_spmm(K, plain, 0, v1, left, nullptr, cheb_epilogue(true, v1, nullptr, a, b));
+        k_orb_left<<<dim3(std::min(kk, 1024), nb), 256, 0, h->stream>>>(kk, velems, h->d_seed.as<int>(), h->d_scal.as<double>(), alat, reinterpret_cast<double2*>(left));
+        const dim3 grid_mf(std::max(1, std::min(mfma_workgroups_per_chain(h, nb), (ostride / GROUP + MF_WAVES - 1) / MF_WAVES)), nb);
+        const dim3 gl = level_grid(h, grid_mf, 0);
+        for (int n = 0; n < lld; ++n) {
+            if (n == 1) {
+                std::swap(v0, v1);
+                kubo_apply_h(K, v0, v1, cheb_epilogue(true, v0, nullptr, a, b));
+            } else if (n > 1) {
+                kubo_apply_h(K, v1, v2, cheb_epilogue(false, v1, v0, a, b));
+                double* o = v0; v0 = v1; v1 = v2; v2 = o;
+            }
+            k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(K.CV, 0, kk, left, v1, h->d_partial.as<double>());
+            int n2 = gl.x;
+            const double* p2 = presum(h, h->d_partial.as<double>(), nb, n2, 1296);
+            k_reduce_gram_out<<<nb, 1024, 0, h->stream>>>(p2, n2, d_out + (size_t)n * BLK, ostr, 1);
+        }
+        HIPCK(h, hipGetLastError());
+        host_out.resize((size_t)nb * ostr * 2);
+        XFER(xfer_d2h(h, host_out.data(), d_out, host_out.size() * sizeof(double)));
+        for (int q = 0; q < nb; ++q) {                                // seed order, like the reference's loop (:2893)
+            const double* src = host_out.data() + (size_t)q * ostr * 2;
+            for (size_t e = 0; e < ostr * 2; ++e) mu_orb[e] += src[e];
+            if (mu_seed) memcpy(mu_seed + (size_t)(c0 + q) * ostr * 2, src, ostr * 2 * sizeof(double));
+        }
+    }
+    hipEvent_t e_end = next_event(h);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = ev_ms(e_begin, e_end);
+    for (auto& pr : spmm_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);
+    h->t_rest_ms = h->t_total_ms - h->t_hop_ms;
+    h->n_hop_launch = (double)spmm_ev.size();
+    h->res_kind = 0;
+    (void)nd;
     return RSREC_OK;
 }
 
@@ -2236,13 +2423,14 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
 extern "C" int rsrec_apply_operator(rsrec_t* h, int vel, const double* v_op, const double* vo_op, const double* psi_in, double* psi_out, double a, double b) {
     int rc = check_ready(h, "rsrec_apply_operator");
     if (rc) return rc;
-    if (!psi_in || !psi_out || (!vel && a == 0.0) || (vel && (!v_op || (h->hoh && !vo_op)))) return fail(h, RSREC_ERR_ARG, "rsrec_apply_operator: bad argument");
+    if (!psi_in || !psi_out || (vel != 1 && a == 0.0) || (vel == 1 && (!v_op || (h->hoh && !vo_op))) || vel < 0 || vel > 2) return fail(h, RSREC_ERR_ARG, "rsrec_apply_operator: bad argument");
     if (!h->s5_built) return fail(h, RSREC_ERR_ARG, "rsrec_apply_operator: lattice has too many neighbour slots for the SpMM kernel");
     HIPCK(h, hipSetDevice(h->device));
     reset_timing(h);
     const int kk = h->kk;
     const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
-    if (vel) { rc = build_kubo_operator(h, 0, v_op, vo_op); if (rc) return rc; if (h->hoh && h->nmax > 0) { rc = build_kubo_hbulk(h); if (rc) return rc; } }
+    if (vel == 1) { rc = build_kubo_operator(h, 0, v_op, vo_op); if (rc) return rc; if (h->hoh && h->nmax > 0) { rc = build_kubo_hbulk(h); if (rc) return rc; } }
+    if (vel == 2 && h->hoh) { rc = build_plain_operator(h); if (rc) return rc; }        // ham_vec_matmul under hoh: the plain operator (recursion.f90:913)
     for (int v = 0; v < 6; ++v) HIPCK(h, h->d_vec[v].reserve(velems * 8));
     for (int v = 0; v < 6; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, velems * 8, h->stream));
     std::vector<int> all(kk);
@@ -2262,8 +2450,11 @@ extern "C" int rsrec_apply_operator(rsrec_t* h, int vel, const double* v_op, con
     XFER(xfer_h2d(h, tmp, psi_in, nd * 8));
     hipEvent_t e0 = next_event(h);
     k_block_transpose<true><<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(tmp), reinterpret_cast<double2*>(in));
-    if (vel) kubo_apply_v(K, h->kubo_op[0], in, out);
-    else {
+    if (vel == 1) kubo_apply_v(K, h->kubo_op[0], in, out);
+    else if (vel == 2 && h->hoh) {
+        kubo_spmm(K, h->orb_plain, 0, in, tmp, nullptr);
+        k_cheb_combine<true><<<(int)std::min<size_t>(4096, (nd + 255) / 256), 256, 0, h->stream>>>(nd, tmp, in, nullptr, out, a, b);
+    } else {
         kubo_apply_h(K, in, tmp);
         k_cheb_combine<true><<<(int)std::min<size_t>(4096, (nd + 255) / 256), 256, 0, h->stream>>>(nd, tmp, in, nullptr, out, a, b);
     }

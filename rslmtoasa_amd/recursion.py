@@ -323,11 +323,35 @@ class Recursion:
         return mu
 
     def ham_vec_matmul(self, psi_in, a, b):
-        """psi_out = (H psi_in - b psi_in)/a on a whole vector psi(18,18,kk) (recursion.f90:913; :785 with hoh)."""
+        """psi_out = (H psi_in - b psi_in)/a on a whole vector psi(18,18,kk) with the PLAIN operator ee + l.s, whatever hoh says
+        (recursion.f90:913-977)."""
+        x = _fc(psi_in, np.complex128)
+        out = np.zeros_like(x)
+        self._check(self._L.rsrec_apply_operator(self._h, 2, None, None, _ptr(x), _ptr(out), float(a), float(b)))
+        return out
+
+    def ham_hoh_vec_matmul(self, psi_in, a, b):
+        """The same with H = h - h o h + e_nu + l.s (recursion.f90:785-911); needs hamiltonian%hoh."""
         x = _fc(psi_in, np.complex128)
         out = np.zeros_like(x)
         self._check(self._L.rsrec_apply_operator(self._h, 0, None, None, _ptr(x), _ptr(out), float(a), float(b)))
         return out
+
+    def chebyshev_orbital_mod(self, cr, alat, seeds=None, per_seed=False):
+        """The moments of chebyshev_orbital_mod (recursion.f90:2834-3049): mu_n_orb(18,18,lld) = (1/kk) sum over all atoms as seeds
+        (`seeds` = a subset: the plain sum over it, not divided), device-resident.  per_seed: also every seed's contribution."""
+        lld = self.control.lld
+        a, b = chebyshev_scaling(self.en.energy_min, self.en.energy_max)
+        kk = self.lattice.kk
+        sd = np.arange(1, kk + 1, dtype=np.int32) if seeds is None else np.ascontiguousarray(seeds, dtype=np.int32)
+        crf = _fc(cr, np.float64)
+        assert crf.shape == (3, kk)
+        mu = np.zeros((18, 18, lld), np.complex128, order="F")
+        ms = np.zeros((18, 18, lld, len(sd)), np.complex128, order="F") if per_seed else None
+        self._check(self._L.rsrec_orbital_moments(self._h, len(sd), _ptr(sd), lld, a, b, _ptr(crf), float(alat), _ptr(mu), _ptr(ms)))
+        if seeds is None:
+            mu = mu / float(kk)                                   # :3006
+        return (mu, ms) if per_seed else mu
 
     def velo_vec_matmul(self, v_op, psi_in, vo_op=None):
         """psi_out = V psi_in (recursion.f90:587; :656 with hoh)."""

@@ -37,8 +37,9 @@ program kubo_gpu_driver
    type(bands), target :: bands_obj
    type(mix), target :: mix_obj
    type(conductivity), target :: conductivity_obj
-   integer :: i
+   integer :: i, elen, estat
    integer(8) :: t0, t1, rate
+   character(len=8) :: envv
 
    rank = 0
    numprocs = 1
@@ -63,6 +64,18 @@ program kubo_gpu_driver
    if (control_obj%nsp == 2 .or. control_obj%nsp == 4) call hamiltonian_obj%build_lsham
    call hamiltonian_obj%build_bulkham()
    recursion_obj = recursion_gpu(hamiltonian_obj, energy_obj)     ! <-- the one-line change
+   ! RSREC_ORBITAL=1: the orbital-moment workflow instead (calculation.f90:1256 after the same set-up): unit 50 is its output
+   call get_environment_variable('RSREC_ORBITAL', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) then
+      call system_clock(t0, rate)
+      call recursion_obj%chebyshev_orbital_mod()
+      call system_clock(t1)
+      flush (50)
+      write (*, '(a,f12.6,a)') 'kubo_gpu_driver: chebyshev_orbital_mod wall time ', real(t1 - t0)/real(rate), ' s'
+      call g_timer%print_report()
+      call rsrec_gpu_shutdown()
+      stop
+   end if
    call system_clock(t0, rate)
    call recursion_obj%compute_moments_stochastic()
    call system_clock(t1)

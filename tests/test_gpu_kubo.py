@@ -87,9 +87,10 @@ def test_whole_vector_products_compose_to_the_moments(name):
     psiref = np.zeros((18, 18, kk), np.complex128, order="F")
     psiref[np.arange(18), np.arange(18), j] = 1.0
     vo_a, vo_b = z.get("vo_a"), z.get("vo_b")
-    left = [psiref, rec.ham_vec_matmul(psiref, a, b)]
+    hv = rec.ham_hoh_vec_matmul if int(z["hoh"]) else rec.ham_vec_matmul        # compute_moments_stochastic picks by hoh (recursion.f90:1126-1130)
+    left = [psiref, hv(psiref, a, b)]
     v0 = rec.velo_vec_matmul(z["v_b"], psiref, vo_b)
-    rights = [rec.velo_vec_matmul(z["v_a"], v0, vo_a), rec.velo_vec_matmul(z["v_a"], rec.ham_vec_matmul(v0, a, b), vo_a)]
+    rights = [rec.velo_vec_matmul(z["v_a"], v0, vo_a), rec.velo_vec_matmul(z["v_a"], hv(v0, a, b), vo_a)]
     ref = z["mu_nm"][:, :, :2, :2, 0]
     scale = np.abs(z["mu_nm"]).max()
     for n in range(2):
@@ -98,8 +99,8 @@ def test_whole_vector_products_compose_to_the_moments(name):
             assert np.abs(mu - ref[:, :, n, m]).max() < RTOL * scale
     # linearity of the product
     x = np.asfortranarray(np.random.default_rng(3).standard_normal((18, 18, kk)) + 0j)
-    y1 = rec.ham_vec_matmul(x, a, b)
-    y2 = rec.ham_vec_matmul(2.5 * x, a, b)
+    y1 = hv(x, a, b)
+    y2 = hv(2.5 * x, a, b)
     assert np.abs(y2 - 2.5 * y1).max() < 1e-12 * np.abs(y1).max()
     rec.close()
 
@@ -112,4 +113,26 @@ def test_kubo_argument_errors():
         rec.compute_moments_stochastic(z["v_a"], z["v_b"], 3, atlist=z["atlist"])
     with pytest.raises(_lib.RsrecError):                      # seed atom outside the lattice
         rec.compute_moments_stochastic(z["v_a"], z["v_b"], 3, vo_a=z["vo_a"], vo_b=z["vo_b"], atlist=[p["nn"].shape[0] + 1])
+    rec.close()
+
+
+@pytest.mark.parametrize("name", KUBO_CASES)
+def test_left_matrix_in_chunks(name):
+    """cond_ll x kk x 5184 B of left vectors do not fit the device for large cells (252 GB for cond_ll = 500 on 10^5 atoms): the left
+    recurrence is then advanced chunk by chunk and every chunk contracted with all right vectors.  Forced here (3 and 4 left vectors
+    at a time, cond_ll = 10): same moments as the one-chunk call, and as the reference."""
+    z = load_golden(name)
+    rec, p = make_rec(z)
+    import rslmtoasa_amd.recursion as R
+    orig = scaled(rec, z)
+    try:
+        args = (z["v_a"], z["v_b"], int(z["cond_ll"]))
+        kw = dict(vo_a=z.get("vo_a"), vo_b=z.get("vo_b"), atlist=z["atlist"])
+        mu1 = rec.compute_moments_stochastic(*args, **kw).copy()
+        for lc in (3, 4):
+            rec.set_option("kubo_lchunk", lc)
+            mu = rec.compute_moments_stochastic(*args, **kw)
+            assert vec_err(mu, mu1) < 1e-13 and vec_err(mu, z["mu_nm"]) < RTOL
+    finally:
+        R.chebyshev_scaling = orig
     rec.close()

@@ -1,0 +1,76 @@
+"""chebyshev_orbital_mod (recursion.f90:2834-3049) as a device-resident loop: rsrec_orbital_moments, its Python / Fortran callers.
+
+What the compiled reference leaves behind for this routine (tests/golden/fccPt_orbital[_hoh].npz, oracle/make_fixtures.py
+run_orbital_case): per seed atom the full-precision sums of left_vec, left_vec1 and left_vec2 it prints (:2972), and unit 50 with the
+trace of the resulting Green function -- which for this non-magnetic case is rounding noise (1e-13).  The moments themselves are a
+local variable.  So: the CPU oracle is pinned on the printed sums (tests/test_oracle_golden.py), the GPU is held to the oracle's
+moments at 1e-10 per seed and in sum, and the reference's unit-50 file is reproduced end to end through the Fortran override.
+Parity of the moments against the reference itself is therefore pinned only through the left vectors: stated, not hidden."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import RTOL, load_golden
+from oracle.make_fixtures import ORBITAL_CASES, patch_namelist
+from rslmtoasa_amd._proc import run_with_unlimited_stack
+from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["fccPt_orbital", "fccPt_orbital_hoh"]
+
+
+def make_rec(z, lld):
+    ham = Hamiltonian(ee=z["ee"], lsham=z["lsham"], eeo=z.get("eeo"), enim=z.get("enim"), hoh=bool(z["hoh"]))
+    lat = Lattice(nn=z["nn"], iz=z["iz"], irec=np.array([1], np.int32), nmax=0, ntype=z["ee"].shape[3])
+    return Recursion(ham, lat, Control(lld=lld, nsp=int(z["nsp"])), Energy(), device=0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_orbital_moments_match_oracle(name, oracle_lib):
+    z = load_golden(name)
+    kk, lld = int(z["kk"]), int(z["lld"])
+    a, b = float(z["acheb"]), float(z["bcheb"])
+    p = {k: z[k] for k in ("nn", "iz", "ee", "lsham", "eeo", "enim") if k in z}
+    p.update(nmax=0, hoh=int(z["hoh"]), nsp=int(z["nsp"]))
+    seeds = np.arange(1, kk + 1, dtype=np.int32)
+    mu_o, ms_o, _ = oracle_lib.Oracle(p).orbital_moments(seeds, lld, a, b, z["cr"], float(z["alat"]), per_seed=True)
+    rec = make_rec(z, lld)
+    import rslmtoasa_amd.recursion as R
+    orig = R.chebyshev_scaling
+    R.chebyshev_scaling = lambda emin, emax: (a, b)
+    try:
+        mu, ms = rec.chebyshev_orbital_mod(z["cr"], float(z["alat"]), per_seed=True)
+        sub = np.array([7, 3, 100], np.int32)
+        mu_sub = rec.chebyshev_orbital_mod(z["cr"], float(z["alat"]), seeds=sub)
+    finally:
+        R.chebyshev_scaling = orig
+    rec.close()
+    scale = np.abs(ms_o).max(axis=(0, 1))                            # per (level, seed); some are exact zeros (a seed at the origin: X|r> = Y|r> = 0)
+    err = np.abs(ms - ms_o).max(axis=(0, 1))
+    assert np.all(err <= RTOL * np.maximum(scale, 1e-3 * scale.max())), float((err / np.maximum(scale, 1e-3 * scale.max())).max())
+    assert np.abs(mu * kk - mu_o).max() <= RTOL * np.abs(ms_o).max()         # the sum over all seeds (cancels to ~0 in parts: absolute bar)
+    assert np.abs(mu_sub - ms_o[:, :, :, sub - 1].sum(axis=3)).max() <= RTOL * np.abs(ms_o).max()
+
+
+def test_fortran_override_reproduces_the_reference_file(tmp_path):
+    """kubo_gpu.x (the reference's modules + type(recursion_gpu)) in the orbital-moment workflow: unit 50 against the compiled
+    reference's file.  Column 1 (E - E_F) to its printed digits; the trace columns are rounding noise in both."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "kubo_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kubo_gpu.x not built (needs the reference sources: build container only)")
+    z = load_golden("fccPt_orbital")
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "scf", "inputs", "conductivity_fccPt"), work)
+    inp = work / "input.nml"
+    inp.write_text(patch_namelist(inp.read_text(), ORBITAL_CASES["fccPt_orbital"][1]))
+    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8", "RSREC_ORBITAL": "1"}, timeout=900, scrub=False)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and "fatal" not in log.lower() and "chebyshev-orbital-gpu" in log, log[-3000:]
+    rows = np.array([[float(v) for v in l.split()] for l in (work / "fort.50").read_text().splitlines() if l.strip()])
+    ref = z["fort50"]
+    assert rows.shape == ref.shape
+    assert np.abs(rows[:, 0] - ref[:, 0]).max() <= 1e-6 * np.abs(ref[:, 0]).max()
+    assert np.abs(ref[:, 2]).max() < 1e-9 and np.abs(rows[:, 2]).max() < 1e-9

@@ -97,10 +97,16 @@ def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, 
     x = np.asfortranarray(rng.standard_normal((18, 18, kk)) + 1j * rng.standard_normal((18, 18, kk)))
     a, b = 1.7, -0.3
     want = ham_vec_numpy(p, x, a, b)
-    got = rec.ham_vec_matmul(x, a, b)
-    rec.close()
+    got = rec.ham_hoh_vec_matmul(x, a, b) if hoh else rec.ham_vec_matmul(x, a, b)
     scale = np.abs(want).max()
     assert np.abs(got - want).max() <= 2e-13 * scale
+    if hoh:
+        # ham_vec_matmul itself is the PLAIN operator ee + l.s also when hoh is set (recursion.f90:913-977; chebyshev_orbital_mod
+        # relies on it, :2950, :2964)
+        plain = (apply_blocks(p, x, False) + np.einsum("ijk,jlk->ilk", np.stack([p["lsham"][:, :, t - 1] for t in p["iz"]], axis=2), x) - b * x) / a
+        got = rec.ham_vec_matmul(x, a, b)
+        assert np.abs(got - plain).max() <= 2e-13 * np.abs(plain).max()
+    rec.close()
 
 
 RECUR_CASES = [  # kk, nslots, ntype, nmax, hoh, collinear
