@@ -447,6 +447,7 @@ def main():
     ham = Hamiltonian(ee=W["ee"], lsham=W["lsham"], eeo=W["eeo"], enim=W["enim"], hall=W["hall"], hallo=W["hallo"], hoh=args.hoh)
     ctl = Control(lld=args.lld, nsp=2, recur="block" if args.recur == "block" else "chebyshev")
     rec = Recursion(ham, lat, ctl, Energy(energy_min=W["emin"], energy_max=W["emax"]), device=device_index, rank=rank, nprocs=world)   # uploads tables: resident before timing
+    rec.set_option("graph", 0)      # a measurement run brackets the H|psi> kernels with HIP events; the captured-graph replay of small batches has none
     if args.kernels:
         rec.set_option("kernels", args.kernels)
     if args.batch:

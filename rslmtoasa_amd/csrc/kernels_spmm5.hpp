@@ -67,10 +67,60 @@ constexpr int S5_HEAD_DOUBLES = 2 * S5_HEAD_TRIPLES * S5_TRIPLE;   // per-chain 
 constexpr int S5_MAXENT = 2 * S4_MAXSLOTS + 2;                     // diagonal and spin-flip part of every slot + the two extra entries
 constexpr int S5_ENTPAD = 8;                                       // null entries behind the list (operands are requested two steps ahead)
 
+// Device-side assembly of the operator streams (our side of the boundary): block (set, tau, slot) = sign * a [+ b] [+ diag * 1],
+// read from the RAW blocks as the caller handed them over (already on the device for the VALU kernel set): h itself, -(h o) with the
+// identity added on-site, e_nu + l.s.  a == nullptr: the class has no such block.
+struct S5Desc { const double* a; const double* b; double sign; double diag; };
+
+__device__ __forceinline__ double s5_desc_value(const S5Desc& D, int ro, int ri, int c /*0 re, 1 im*/) {
+    double v = D.sign * D.a[2 * (ro + 18 * ri) + c];
+    if (D.b) v = v + D.b[2 * (ro + 18 * ri) + c];
+    if (D.diag != 0.0 && ro == ri && c == 0) v = v + D.diag;
+    return v;
+}
+
+// One thread per fragment double: grid (ntr, 2 sigma_out, nset * ntau), 640 threads.  Same index arithmetic as Spmm5Operator::emit_stream
+// (the host version, kept for the general tables of the Kubo / local-axis paths): bitwise the same streams.
+__global__ __launch_bounds__(640) void k_s5_emit(const S5Desc* __restrict__ desc, const int* __restrict__ meta, int meta_stride, int nfs, int null_col, int ntr,
+                                                 double* __restrict__ frag) {
+    const int t = blockIdx.x, sig = blockIdx.y, st = blockIdx.z;
+    const int* codes = meta + (size_t)st * meta_stride + 2;
+    const S5Desc* D = desc + (size_t)st * nfs;
+    const int e0 = threadIdx.x;                               // 0..639 inside the triple
+    const int K = e0 < 256 ? 0 : e0 < 512 ? 1 : 2;
+    const int r = e0 - (K == 0 ? 0 : K == 1 ? 256 : 512);
+    int q, l, e;
+    if (K < 2) { q = r >> 7; l = (r & 127) >> 1; e = r & 1; } else { q = r >> 6; l = r & 63; e = 0; }
+    const int k = l >> 4, rho = q == 0 ? (l & 15) : 16 + (l & 3);
+    // decode20
+    const int stq = rho >> 2, ll = rho & 3;
+    int po = 0, mo = 0;
+    bool row = true;
+    if (stq < 4) { po = stq & 1; mo = 4 * (stq >> 1) + ll; } else if (ll < 2) { po = ll; mo = 8; } else row = false;
+    const int o0 = 10 * t + (K == 0 ? 0 : K == 1 ? 4 : 8);
+    const int o = K < 2 ? o0 + k : o0 + (k >> 1);
+    const int pi = K < 2 ? e : (k & 1);
+    double v = 0.0;
+    if (row) {
+        const int j = o / 9, code = codes[j], col = code & 255, flip = code >> 8;
+        if (col != null_col && D[col].a) {
+            const int so = sig, si = flip ? 1 - sig : sig, mi = o % 9;
+            const int ro = 9 * so + mo, ri = 9 * si + mi;
+            const double hr = s5_desc_value(D[col], ro, ri, 0), hi = s5_desc_value(D[col], ro, ri, 1);
+            v = (po == pi) ? hr : (po == 0 ? -hi : hi);
+        }
+    }
+    frag[(((size_t)st * 2 + sig) * ntr + t) * S5_TRIPLE + e0] = v;
+}
+
 struct Spmm5Operator {
     double* d_frag = nullptr;    // [set][tau][sigma_out][ntr][640]
     int* d_meta = nullptr;       // [set][tau][META]: number of steps, number of extra entries (0 / 2), entry codes column | flip << 8
     size_t frag_bytes = 0, meta_bytes = 0;
+    S5Desc* d_desc = nullptr;    // device-side assembly: [set][tau][nslots + 1]
+    size_t desc_bytes = 0;
+    std::vector<signed char> sched_sig;   // block structure (absent / spin-diagonal / spin-mixing per block) the uploaded schedule was built for
+    int sched_dims[3] = {0, 0, 0};
     int ntau = 0, nslots = 0, have_o = 0, ntr = 0, spin_mixing = 0;   // spin_mixing: some regular (hopping) block has a spin-flip part
     static constexpr int META = 2 + S5_MAXENT + S5_ENTPAD;
     struct Entry { const double* blk; int col; int flip; };        // blk == nullptr: null entry (zero fragments, reads the zero block)
@@ -82,7 +132,9 @@ struct Spmm5Operator {
     void release() {
         if (d_frag) (void)hipFree(d_frag);
         if (d_meta) (void)hipFree(d_meta);
-        d_frag = nullptr; d_meta = nullptr; frag_bytes = meta_bytes = 0;
+        if (d_desc) (void)hipFree(d_desc);
+        d_frag = nullptr; d_meta = nullptr; d_desc = nullptr; frag_bytes = meta_bytes = desc_bytes = 0;
+        sched_sig.clear();
     }
     // row rho (0..19) of an output spin's padded real form: rho = 4 s + l; s < 4 -> (part s & 1, m = 4 (s >> 1) + l); s = 4 -> l = 0: (re, m = 8),
     // l = 1: (im, m = 8), l = 2, 3: padding.  (The 16x16x4 result register j of lane row l4 is row l4 + 4 j: registers (2 p, 2 p + 1) are the
@@ -128,58 +180,46 @@ struct Spmm5Operator {
             }
         }
     }
-    // General table: blk[(set * ntau + tau) * (nslots + 1) + s] = column-major interleaved 18x18 complex block of operator class tau,
-    // slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes nothing and is
-    // not scheduled).  Schedule: the two extra entries first (spin-diagonal and spin-flip part; a null entry if the block has no such
-    // part -- the kernel switches from the second input to the first after orbital 18, a step boundary), then the spin-diagonal part
-    // of every block, plus the spin-flip part of the blocks that have one.
-    const char* build_custom(int nslots_lat, int ntau_, int nset, const std::vector<const double*>& blk) {
+    // Schedule of every (set, tau) from the block STRUCTURE alone: kind[(set * ntau + tau) * (nslots + 1) + s] = -1 absent, 0 spin-diagonal,
+    // 1 spin-mixing (s = nslots: the extra on-site slot that reads the second input vector).  The two extra entries first (spin-diagonal
+    // and spin-flip part; a null entry if the block has no such part -- the kernel switches from the second input to the first after
+    // orbital 18, a step boundary), then the spin-diagonal part of every block, plus the spin-flip part of the blocks that have one.
+    // Fills meta / ksteps / mixing / ntr and uploads the meta table; `sched` (optional) receives the entry lists as (column, flip) pairs,
+    // column -1 = null entry.  Unchanged structure (every SCF iteration after the first): nothing is rebuilt or uploaded.
+    const char* make_schedule(int nslots_lat, int ntau_, int nset, const std::vector<signed char>& kind, std::vector<std::vector<std::pair<int, int>>>* sched_out) {
         if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
+        const bool same = !sched_out && d_meta && sched_dims[0] == nslots_lat && sched_dims[1] == ntau_ && sched_dims[2] == nset && sched_sig == kind;
+        if (same) return nullptr;
         ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0; spin_mixing = 0;
         const int nfs = nslots + 1, null_col = nslots + 1;
-        std::vector<std::vector<Entry>> sched((size_t)nset * ntau);
+        std::vector<std::vector<std::pair<int, int>>> sched((size_t)nset * ntau);
         std::vector<int> meta((size_t)nset * ntau * META, 0);
-        head_main.assign((size_t)nset * ntau, Head());
         ksteps.assign((size_t)nset * ntau, 0);
-        mixing.assign((size_t)nset * ntau * nfs, -1);
-        for (size_t q = 0; q < mixing.size(); ++q)
-            if (blk[q]) mixing[q] = Spmm4Operator::pattern_of(blk[q]) == 0 ? 1 : 0;
+        mixing = kind;
         int maxent = 0;
         for (int set = 0; set < nset; ++set)
             for (int tau = 0; tau < ntau; ++tau) {
-                std::vector<Entry>& E = sched[(size_t)set * ntau + tau];
-                const double* const* B = blk.data() + ((size_t)set * ntau + tau) * nfs;
+                std::vector<std::pair<int, int>>& E = sched[(size_t)set * ntau + tau];
+                const signed char* Kd = kind.data() + ((size_t)set * ntau + tau) * nfs;
                 int* M = meta.data() + ((size_t)set * ntau + tau) * META;
-                if (B[nslots]) {
-                    E.push_back({B[nslots], nslots, 0});
-                    E.push_back({Spmm4Operator::pattern_of(B[nslots]) == 0 ? B[nslots] : nullptr, nslots, 1});
+                if (Kd[nslots] >= 0) {
+                    E.push_back({nslots, 0});
+                    E.push_back({Kd[nslots] == 1 ? nslots : -1, 1});
                     M[1] = 2;
                 }
                 for (int s = 0; s < nslots; ++s) {
-                    if (!B[s]) continue;
-                    if ((int)E.size() == M[1]) {
-                        Head& H = head_main[(size_t)set * ntau + tau];
-                        H.blk.assign(B[s], B[s] + 2 * BLK); H.flip = 0; H.valid = true;
-                    }
-                    E.push_back({B[s], s, 0});
-                    if (Spmm4Operator::pattern_of(B[s]) == 0) { E.push_back({B[s], s, 1}); if (s > 0) spin_mixing = 1; }
+                    if (Kd[s] < 0) continue;
+                    E.push_back({s, 0});
+                    if (Kd[s] == 1) { E.push_back({s, 1}); if (s > 0) spin_mixing = 1; }
                 }
                 M[0] = steps_of((int)E.size());
                 ksteps[(size_t)set * ntau + tau] = 5 * (M[0] / 3) + 2 * (M[0] % 3);
                 for (int j = 0; j < S5_MAXENT + S5_ENTPAD; ++j)
-                    M[2 + j] = j < (int)E.size() ? ((E[j].blk ? E[j].col : null_col) | (E[j].flip << 8)) : null_col;
+                    M[2 + j] = j < (int)E.size() ? ((E[j].first >= 0 ? E[j].first : null_col) | (E[j].second << 8)) : null_col;
                 maxent = std::max(maxent, (int)E.size());
             }
         ntr = (9 * maxent + 9) / 10 + 1;                       // + one zero triple: the last steps request operands beyond the end
-        const size_t per_sig = (size_t)ntr * S5_TRIPLE, per_set = (size_t)ntau * 2 * per_sig;
-        std::vector<double> host(per_set * nset, 0.0);
-        for (int set = 0; set < nset; ++set)
-            for (int tau = 0; tau < ntau; ++tau)
-                for (int sig = 0; sig < 2; ++sig) {
-                    const std::vector<Entry>& E = sched[(size_t)set * ntau + tau];
-                    emit_stream(E, sig, 0, (9 * (int)E.size() + 9) / 10, host.data() + set * per_set + ((size_t)tau * 2 + sig) * per_sig);
-                }
-        const size_t need = host.size() * sizeof(double), mneed = meta.size() * sizeof(int);
+        const size_t need = (size_t)nset * ntau * 2 * ntr * S5_TRIPLE * sizeof(double), mneed = meta.size() * sizeof(int);
         if (need > frag_bytes) {
             if (d_frag) (void)hipFree(d_frag);
             d_frag = nullptr; frag_bytes = 0;
@@ -192,8 +232,42 @@ struct Spmm5Operator {
             if (hipMalloc(reinterpret_cast<void**>(&d_meta), mneed) != hipSuccess) return "hipMalloc of spmm5 schedule failed";
             meta_bytes = mneed;
         }
-        if (hipMemcpy(d_frag, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 fragments failed";
         if (hipMemcpy(d_meta, meta.data(), mneed, hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 schedule failed";
+        sched_sig = kind; sched_dims[0] = nslots_lat; sched_dims[1] = ntau_; sched_dims[2] = nset;
+        if (sched_out) sched_out->swap(sched);
+        return nullptr;
+    }
+    static std::vector<signed char> kinds_of(const std::vector<const double*>& blk) {
+        std::vector<signed char> kind(blk.size(), -1);
+        for (size_t q = 0; q < blk.size(); ++q)
+            if (blk[q]) kind[q] = Spmm4Operator::pattern_of(blk[q]) == 0 ? 1 : 0;
+        return kind;
+    }
+    // General table: blk[(set * ntau + tau) * (nslots + 1) + s] = column-major interleaved 18x18 complex block of operator class tau,
+    // slot s (s = nslots: the extra on-site slot that reads the second input vector), or nullptr = absent (contributes nothing and is
+    // not scheduled).  Fragments swizzled on the HOST (the general tables of the Kubo velocity operators, the local-axis operator, the
+    // plain operator under hoh; the Hamiltonian itself takes build() -> device assembly).
+    const char* build_custom(int nslots_lat, int ntau_, int nset, const std::vector<const double*>& blk) {
+        std::vector<std::vector<std::pair<int, int>>> sched;
+        if (const char* msg = make_schedule(nslots_lat, ntau_, nset, kinds_of(blk), &sched)) return msg;
+        const int nfs = nslots + 1;
+        head_main.assign((size_t)nset * ntau, Head());
+        const size_t per_sig = (size_t)ntr * S5_TRIPLE, per_set = (size_t)ntau * 2 * per_sig;
+        std::vector<double> host(per_set * nset, 0.0);
+        for (int set = 0; set < nset; ++set)
+            for (int tau = 0; tau < ntau; ++tau) {
+                const double* const* B = blk.data() + ((size_t)set * ntau + tau) * nfs;
+                std::vector<Entry> E;
+                for (const auto& en : sched[(size_t)set * ntau + tau]) E.push_back({en.first >= 0 ? B[en.first] : nullptr, en.first >= 0 ? en.first : nslots, en.second});
+                const int nextra = (B[nslots] != nullptr) ? 2 : 0;
+                if ((int)E.size() > nextra) {
+                    Head& H = head_main[(size_t)set * ntau + tau];
+                    H.blk.assign(E[nextra].blk, E[nextra].blk + 2 * BLK); H.flip = 0; H.valid = true;
+                }
+                for (int sig = 0; sig < 2; ++sig)
+                    emit_stream(E, sig, 0, (9 * (int)E.size() + 9) / 10, host.data() + set * per_set + ((size_t)tau * 2 + sig) * per_sig);
+            }
+        if (hipMemcpy(d_frag, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return "upload of spmm5 fragments failed";
         return nullptr;
     }
     // Head of the stream of (set, tau) with `extra` as the block of the extra on-site slot (both spin parts scheduled): the per-chain
@@ -208,22 +282,32 @@ struct Spmm5Operator {
     // ONE SpMM pass over hpsi = h psi plus one extra on-site slot reading psi gives the whole
     //   H psi = hpsi - (h o) hpsi + (e_nu + l.s) psi   (recursion.f90:1543):
     // slot 0 -> 1 - (h o)_0,  slot s -> -(h o)_s,  slot `nslots` (extra) -> enim + lsham of the atom's type.
+    // st / loc / eeo / hallo / enim / lsham: host arrays (st, loc with l.s folded into slot 0 when !hoh).  dev != nullptr: the same arrays
+    // on the device, [0] st, [1] loc, [2] eeo, [3] hallo, [4] enim, [5] lsham -- the streams are then assembled THERE (k_s5_emit) from
+    // descriptors, and the host only looks at the block structure; with an unchanged structure (every SCF iteration after the first)
+    // a call is one small descriptor upload + one kernel.
     const char* build(int nslots_lat, int hstride, int ntype, int nmax, int hoh, const double* st, const double* loc, const double* eeo, const double* hallo,
-                      const double* enim, const double* lsham, const int* iz0) {
+                      const double* enim, const double* lsham, const int* iz0, const double* const* dev = nullptr, hipStream_t stream = nullptr) {
         const int nt = nmax + ntype, nset = hoh ? 2 : 1, nfs = nslots_lat + 1;
         const size_t B = 2 * (size_t)BLK;
         std::vector<const double*> blk((size_t)nset * nt * nfs, nullptr);
         std::vector<double> tmp((size_t)(hoh ? nt * nfs : 0) * B, 0.0);
+        std::vector<S5Desc> desc(dev ? (size_t)nset * nt * nfs : 0, S5Desc{nullptr, nullptr, 1.0, 0.0});
         for (int tau = 0; tau < nt; ++tau)
             for (int s = 0; s < nslots_lat; ++s) {
-                const double* h0 = tau < nmax ? loc + B * (s + (size_t)hstride * tau) : st + B * (s + (size_t)hstride * (tau - nmax));
+                const size_t off = tau < nmax ? B * (s + (size_t)hstride * tau) : B * (s + (size_t)hstride * (tau - nmax));
+                const double* h0 = (tau < nmax ? loc : st) + off;
                 blk[(size_t)tau * nfs + s] = h0;
+                if (dev) desc[(size_t)tau * nfs + s] = S5Desc{(tau < nmax ? dev[1] : dev[0]) + off, nullptr, 1.0, 0.0};
                 if (hoh) {
-                    const double* ho = tau < nmax ? hallo + B * (s + (size_t)hstride * tau) : eeo + B * (s + (size_t)hstride * (tau - nmax));
-                    double* d = tmp.data() + B * ((size_t)tau * nfs + s);
-                    for (size_t e = 0; e < B; ++e) d[e] = -ho[e];
-                    if (s == 0) for (int q = 0; q < NB; ++q) d[2 * (q + NB * q)] += 1.0;
-                    blk[((size_t)nt + tau) * nfs + s] = d;
+                    const double* ho = (tau < nmax ? hallo : eeo) + off;
+                    if (dev) { blk[((size_t)nt + tau) * nfs + s] = ho; desc[((size_t)nt + tau) * nfs + s] = S5Desc{(tau < nmax ? dev[3] : dev[2]) + off, nullptr, -1.0, s == 0 ? 1.0 : 0.0}; }
+                    else {
+                        double* d = tmp.data() + B * ((size_t)tau * nfs + s);
+                        for (size_t e = 0; e < B; ++e) d[e] = -ho[e];
+                        if (s == 0) for (int q = 0; q < NB; ++q) d[2 * (q + NB * q)] += 1.0;
+                        blk[((size_t)nt + tau) * nfs + s] = d;
+                    }
                 }
             }
         if (hoh)
@@ -232,8 +316,24 @@ struct Spmm5Operator {
                 double* d = tmp.data() + B * ((size_t)tau * nfs + nslots_lat);
                 for (size_t e = 0; e < B; ++e) d[e] = enim[B * ty + e] + lsham[B * ty + e];
                 blk[((size_t)nt + tau) * nfs + nslots_lat] = d;
+                if (dev) desc[((size_t)nt + tau) * nfs + nslots_lat] = S5Desc{dev[4] + B * ty, dev[5] + B * ty, 1.0, 0.0};
             }
-        return build_custom(nslots_lat, nt, nset, blk);
+        if (!dev) return build_custom(nslots_lat, nt, nset, blk);
+        // device assembly: the structure from the host copies (the negation and the added identity of set 1 change no spin-flip entry)
+        if (const char* msg = make_schedule(nslots_lat, nt, nset, kinds_of(blk), nullptr)) return msg;
+        head_main.assign((size_t)nset * nt, Head());
+        const size_t dneed = desc.size() * sizeof(S5Desc);
+        if (dneed > desc_bytes) {
+            if (d_desc) (void)hipFree(d_desc);
+            d_desc = nullptr; desc_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&d_desc), dneed) != hipSuccess) return "hipMalloc of spmm5 block descriptors failed";
+            desc_bytes = dneed;
+        }
+        if (hipMemcpyAsync(d_desc, desc.data(), dneed, hipMemcpyHostToDevice, stream) != hipSuccess) return "upload of spmm5 block descriptors failed";
+        if (hipStreamSynchronize(stream) != hipSuccess) return "upload of spmm5 block descriptors failed";      // desc is a local
+        k_s5_emit<<<dim3(ntr, 2, nset * nt), S5_TRIPLE, 0, stream>>>(d_desc, d_meta, META, nfs, nslots_lat + 1, ntr, d_frag);
+        if (hipGetLastError() != hipSuccess) return "launch of the operator-stream assembly failed";
+        return nullptr;
     }
     // the one operator class of set `set` that has a schedule, or -1 if several have (then groups of different classes meet in a launch)
     int single_class(int set) const {

@@ -89,6 +89,7 @@ struct rsrec_handle {
     bool s4_attr = false;               // k_spmm4's and k_terminator's LDS opt-ins, per handle for the same reason
     size_t term_attr_lds = 0;
     std::vector<double> host_ee, host_lsham, host_eeo, host_enim, host_hall, host_hallo;   // operator arrays as last set (Kubo operator tables; local-axis runs)
+    std::vector<double> host_st, host_loc;   // ee / hall with l.s folded into the on-site block when !hoh (what d_hst / d_hloc hold)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
@@ -101,8 +102,9 @@ struct rsrec_handle {
     size_t pin_bytes = 0;
     DevBuf d_frags, d_vec[6], d_order, d_cum, d_partial, d_partial2, d_coefA, d_coefB, d_bmats, d_status, d_seed, d_seedcoef, d_mu, d_scal, d_zsqr;
     // options
-    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 1, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
+    long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
+    long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
     int n_kubo_left_chunks = 0;
     long opt_orth3 = 1;          // k_mfma_orth3: 1 one 512-register wave per SIMD (tables in registers), 2 two waves per SIMD (tables in LDS)
@@ -391,6 +393,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
+    else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -563,18 +566,17 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
             HIPCK(h, hipMemcpy(h->d_holoc.p, hallo, B * nslots * nmax * 8, hipMemcpyHostToDevice));
         }
     }
-    // MFMA-fragment form of the same operator tables
+    // MFMA-fragment form of the same operator tables.  k_spmm5's streams are assembled on the DEVICE from the raw blocks uploaded above
+    // (Spmm5Operator::build -> k_s5_emit; option s5_host_emit = 1: on the host, the round-2 path, kept as the cross-check).  k_spmm4's
+    // tables (small launches of the plain operator only) are built when a call first needs them (ensure_s4).
     {
-        const char* msg = nullptr;
         h->s4_built_split = 0; h->s5_built = 0;
         if (h->nslots + 1 <= S4_MAXSLOTS) {
-            const int nsplit = 1;
-            msg = h->s4_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
-                                 (hoh && nmax > 0) ? hallo : nullptr, nsplit);
-            if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
-            h->s4_built_split = nsplit;
-            msg = h->s5_op.build(h->nslots, nslots, ntype, nmax, h->hoh, st.data(), nmax > 0 ? loc.data() : nullptr, hoh ? eeo : nullptr,
-                                 (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham, h->iz0.data());
+            h->host_st.swap(st);
+            h->host_loc.swap(loc);
+            const double* dev[6] = {h->d_hst.as<double>(), h->d_hloc.as<double>(), h->d_host.as<double>(), h->d_holoc.as<double>(), h->d_enim.as<double>(), h->d_lsham.as<double>()};
+            const char* msg = h->s5_op.build(h->nslots, nslots, ntype, nmax, h->hoh, h->host_st.data(), nmax > 0 ? h->host_loc.data() : nullptr, hoh ? eeo : nullptr,
+                                             (hoh && nmax > 0) ? hallo : nullptr, hoh ? enim : nullptr, lsham, h->iz0.data(), h->opt_s5_host_emit ? nullptr : dev, h->stream);
             if (msg) return fail(h, RSREC_ERR_DEVICE, "rsrec_set_hamiltonian: %s", msg);
             h->s5_built = 1;
         }
@@ -928,7 +930,16 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
-bool spmm4_usable(const rsrec_t* h) { return h->s4_built_split && (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32); }
+bool spmm4_usable(const rsrec_t* h) { return h->s5_built && !h->hoh && (size_t)(h->kk + 1) * BLD * sizeof(double) < ((size_t)1 << 32); }
+
+// k_spmm4's fragment tables of the operator as last set (plain operator only: hoh calls always take k_spmm5), built on first use
+int ensure_s4(rsrec_t* h) {
+    if (h->s4_built_split) return RSREC_OK;
+    const char* msg = h->s4_op.build(h->nslots, h->hslots, h->ntype, h->nmax, 0, h->host_st.data(), h->nmax > 0 ? h->host_loc.data() : nullptr, nullptr, nullptr, 1);
+    if (msg) return fail(h, RSREC_ERR_DEVICE, "k_spmm4 operator tables: %s", msg);
+    h->s4_built_split = 1;
+    return RSREC_OK;
+}
 
 // small-launch SpMM on LayoutRM vectors: out = sum_slots H_slot in_nbr, four waves share one group of atoms (k_spmm4<4>)
 int s4_prepare(rsrec_t* h) {
@@ -956,11 +967,14 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const int nlev = (hoh ? 2 * nsteps : nsteps) + 1;
     const size_t velems = (size_t)(kk + 1) * BLD;           // doubles per chain per vector (+1: the all-zero block)
     int nvec = MFMA ? 4 : (hoh ? 3 : 2);
-    // Matrix-core set: large launches, hoh and local-axis runs use k_spmm5 with every vector in the CI layout; small launches of the
-    // plain operator keep the cooperative k_spmm4<4> on LayoutRM (option spmm5: 0 = never, 1 = by launch size, 2 = always)
+    // Matrix-core set: k_spmm5 with every vector in the CI layout (option spmm5 = 2, the default since round 3: with the operator
+    // streams assembled on the device a call no longer pays k_spmm4's host swizzle -- 3 ms per SCF iteration on the 18 operator classes
+    // of B2FeCo, tools/time_set_hamiltonian.py -- and k_spmm5 is as fast on one chain).  spmm5 = 1: small launches of the plain operator
+    // take the cooperative k_spmm4<4> on LayoutRM (kept as the cross-check of the parity tests); 0: k_spmm4 whenever it can
     const bool large = (long)std::min(nchains, 64) * (kk / GROUP + 1) >= 4096;
     const int ci = (MFMA && (hoh || rot || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && large) || !spmm4_usable(h))) ? 1 : 0;   // vectors of this call are CI (else LayoutRM / LayoutCM)
     if (rot && !MFMA) return fail(h, RSREC_ERR_ARG, "local-axis recursion needs the matrix-core kernel set (option kernels = 0 or 2)");
+    if (MFMA && !ci) { const int rc4 = ensure_s4(h); if (rc4) return rc4; }
     const int ntau = h->nmax + h->ntype;
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
     const int la_fps = S5_HEAD_DOUBLES;
@@ -1820,6 +1834,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const bool use_kp = MFMA && (hoh || h->opt_spmm5 == 2 || (h->opt_spmm5 == 1 && (long)std::min(nsites, 64) * (kk / GROUP + 1) >= 4096) || !spmm4_usable(h));
     const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
     const int ci = use_kp ? 1 : 0;                              // vectors of this call are CI (else LayoutRM / LayoutCM)
+    if (MFMA && !use_kp) { rc = ensure_s4(h); if (rc) return rc; }
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;

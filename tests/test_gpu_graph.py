@@ -65,3 +65,28 @@ def test_graph_on_the_reference_cases(name):
         rec.recur_b()
         assert rel_err(rec.a_b, g["a_b"]) < RTOL and rel_err(rec.b2_b, g["b2_b"]) < RTOL
     rec.close()
+
+
+@pytest.mark.parametrize("name", ["B2FeCo_block_hoh", "B2FeCo_block", "fccCu001_block_hoh", "bccFe_nsp4_block", "bccFe_nsp2_block_hoh"])
+def test_device_assembled_operator_streams_equal_the_host_swizzle(name):
+    """rsrec_set_hamiltonian assembles k_spmm5's operator streams on the device from the raw blocks (k_s5_emit; SURVEY 8 f2, our side of
+    the boundary: 6.8 ms of host swizzle per call on the 18 operator classes of B2FeCo, more than its recursion call).  Option
+    s5_host_emit = 1 keeps the host swizzle: both must give bit-identical coefficients (the streams are the same numbers), also after
+    the operator's values change while its block structure stays (the cached-schedule path of every later SCF iteration)."""
+    g = load_golden_with_inputs(name)
+    rec = Recursion(*objects_from(problem_dict(g), g["irec"], int(g["lld"]), nsp=int(g["nsp"])), device=0)
+    rec.set_option("spmm5", 2)
+    rec.set_option("graph", 0)
+    out = {}
+    for scale in (1.0, 0.9):
+        rec.hamiltonian.ee = g["ee"] * scale
+        for host in (1, 0, 0):
+            rec.set_option("s5_host_emit", host)
+            rec.update_hamiltonian()
+            rec.recur_b()
+            out.setdefault(scale, []).append((rec.a_b.copy(), rec.b2_b.copy()))
+        (a1, b1), (a2, b2), (a3, b3) = out[scale]
+        assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(a1, a3) and np.array_equal(b1, b3)
+    assert rel_err(out[1.0][1][0], g["a_b"]) < RTOL and rel_err(out[1.0][1][1], g["b2_b"]) < RTOL
+    assert np.abs(out[0.9][1][0] - out[1.0][1][0]).max() > 1e-4
+    rec.close()

@@ -26,6 +26,7 @@ def select_kernels(rec, variant):
         rec.set_option("spmm5", 2)
     else:
         rec.set_option("kernels", variant)
+        rec.set_option("spmm5", 1)          # by launch size: these small fixtures then run the cooperative k_spmm4<4> on LayoutRM (the default is k_spmm5 always)
 
 
 def make(p, irec, lld, **kw):

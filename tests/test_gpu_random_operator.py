@@ -45,8 +45,7 @@ def test_full_complex_hopping_blocks(seed, hoh, variant, oracle_lib):
     lld = 8
     rec = Recursion(*objects_from(p, sites, lld, nsp=4, emin=-6.0, emax=6.0), device=0)
     rec.set_option("kernels", 2)
-    if variant == "kp":
-        rec.set_option("spmm5", 2)
+    rec.set_option("spmm5", 2 if variant == "kp" else 1)        # kp: k_spmm5 (the default); coop: k_spmm4<4> (small launches of the plain operator when asked for)
     rec.recur_b()
     rec.chebyshev_recur()
     o = oracle_lib.Oracle(p)

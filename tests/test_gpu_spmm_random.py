@@ -133,6 +133,7 @@ def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, colli
         rec.set_option("spmm5", 2)
     else:
         rec.set_option("kernels", variant)
+        rec.set_option("spmm5", 1)
     o = oracle_lib.Oracle(p)
     rec.recur_b()
     a_o, b_o = o.block_lanczos(irec, lld)
