@@ -165,7 +165,18 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
     gram_block_out(A, lds, partial + ((size_t)chain * gridDim.x + blockIdx.x) * 1296, false);
 }
 
-struct SpmmDims { int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; const int* obase; int nchains = 0; };
+struct SpmmDims {
+    int kk, nslots, nmax, nlev, cpo, ostride, level; size_t vstride; const int* obase; int nchains = 0;
+    // operators with several classes of atoms (k_spmm5): the list of ALL atoms (the one a chain uses once its region covers the lattice,
+    // obase == sat_base) is sorted by class, so every class is one run of groups, the same for every chain.
+    //   run_hi > 0 : this launch serves the groups [run_lo, run_hi) of that list only, and only chains that use it (the launches with the
+    //                run's operator stream in LDS);
+    //   nskip > 0  : this launch leaves the runs skip_lo/hi[] of that list to such launches (chains on their level-major list: everything).
+    //   nruns > 0  : ONE persistent launch serves up to four runs: the workgroup rows run_row0[r] .. run_row0[r + 1] - 1 (rows of 8 or 16
+    //                workgroups, the kernel's XCD mapping) hold the stream of class run_tau[r] and take the groups [run_glo[r], run_ghi[r]).
+    int sat_base = 0, run_lo = 0, run_hi = 0, nskip = 0, skip_lo[4] = {0, 0, 0, 0}, skip_hi[4] = {0, 0, 0, 0};
+    int nruns = 0, run_tau[4] = {0, 0, 0, 0}, run_glo[4] = {0, 0, 0, 0}, run_ghi[4] = {0, 0, 0, 0}, run_row0[5] = {0, 0, 0, 0, 0};
+};
 
 // ---- reductions of the 36x36 real partials ----------------------------------------------------------------------------
 // returns C[cp + 18 c] (complex) for tid < 324:  C_re = G[re cp][re c] + G[im cp][im c],  C_im = G[re cp][im c] - G[im cp][re c]

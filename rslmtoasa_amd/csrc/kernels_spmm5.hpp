@@ -572,6 +572,18 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = LDSA ? (int)((spin_by_xcd ? blockIdx.x : (blockIdx.x >> 3)) & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
     const int WGG = LDSA ? (int)(blockDim.x >> 6) : S5_WG_GROUPS;     // groups per workgroup (LDSA: one per wave; 8 waves, or 4 when the launch leaves half of the CU to other kernels)
+    // several class runs in one persistent launch: this workgroup's run, and its place among the workgroups of that run
+    int bxl = blockIdx.x, gdxl = gridDim.x, run_lo = D.run_lo, run_hi = D.run_hi, qrun = 0;
+    if (LDSA && D.nruns > 0) {
+        const int row = spin_by_xcd ? 8 : 16, rowi = (int)blockIdx.x / row;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (q < D.nruns && rowi >= D.run_row0[q]) r = q;
+        lds_tau = D.run_tau[r]; run_lo = D.run_glo[r]; run_hi = D.run_ghi[r];
+        bxl = (int)blockIdx.x - row * D.run_row0[r];
+        gdxl = row * (D.run_row0[r + 1] - D.run_row0[r]);
+        qrun = r;
+    }
     if constexpr (LDSA) {
         const s5_d2* __restrict__ src = reinterpret_cast<const s5_d2*>(frag + ((size_t)lds_tau * 2 + sig) * ntr * S5_TRIPLE);
         s5_d2* dst = reinterpret_cast<s5_d2*>(s5_lds);
@@ -599,8 +611,16 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #pragma unroll 1
     for (int chain = blockIdx.y; chain < D.nchains; chain += gridDim.y) {
     const int count = cum[(chain / D.cpo) * D.nlev + D.level];
-    const int ngroups = count / GROUP;
-    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + D.obase[(chain / D.cpo) * D.nlev + D.level];
+    int ngroups = count / GROUP;
+    const int ob = D.obase[(chain / D.cpo) * D.nlev + D.level];
+    const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + ob;
+    const bool on_full_list = D.sat_base > 0 && ob == D.sat_base;          // the class-sorted list of all atoms
+    if (run_hi > 0) {                                                       // one class run of that list (its stream is what this workgroup holds in LDS)
+        if (!on_full_list) continue;
+        order += (size_t)run_lo * GROUP;
+        ngroups = run_hi - run_lo;
+    }
+    const bool skipping = D.nskip > 0 && on_full_list;
     const size_t vo = (size_t)chain * D.vstride;
     const char* __restrict__ inb = reinterpret_cast<const char*>(in_all + vo);
     const char* __restrict__ in2b = TWO ? reinterpret_cast<const char*>(in2_all + vo) : nullptr;
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     int g, gend, gstep, glo = 0;
     bool dynamic = false;
     {
-        const int bx = blockIdx.x;
+        const int bx = bxl;
         const int need = (ngroups + WGG - 1) / WGG;               // workgroups one round of the chain takes (per spin for LDSA)
         if constexpr (!LDSA) {
             const int nbx = max(1, min((int)gridDim.x, need));
@@ -633,7 +653,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             // whole rows of 8 (spin_by_xcd) or 16 (both spins per XCD) workgroups; a chain too short for one row per XCD chunk is dealt
             // over the first row as one list
             const int row = spin_by_xcd ? 8 : 16;
-            const int nbx = max(row, min((int)gridDim.x / row * row, (2 * need + row - 1) / row * row));
+            const int nbx = max(row, min(gdxl / row * row, (2 * need + row - 1) / row * row));
             if (bx >= nbx) continue;
             const int xcd = bx & 7, j = bx >> 3;
             if (2 * need <= row) {                               // short chain: the first row, 4 (8) workgroups per spin
@@ -656,9 +676,10 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     // queue mode (LDSA, grid.x a multiple of 8, few long-lived workgroups): the waves of XCD x take the groups of its chunk one at a
     // time from the chain's counter x -- the copy of the operator stream into LDS is paid once per workgroup, the balancing stays
     // dynamic at the granularity of one group; every wave leaves when the counters of all its chains have run past their chunks
-    int* __restrict__ ctr = dynamic ? queue + (size_t)chain * 16 + 2 * (blockIdx.x & 7) + (spin_by_xcd ? 0 : sig) : nullptr;
+    int* __restrict__ ctr = dynamic ? queue + ((size_t)qrun * D.nchains + chain) * 16 + 2 * (blockIdx.x & 7) + (spin_by_xcd ? 0 : sig) : nullptr;
     // (issuing the pull for the NEXT group before the current group's work was tried: the returning atomic is the oldest entry of the
     // in-order vmcnt queue and every operand wait of the first steps then waits for it as well -- 19 % slower)
+    // (round 3: the pull issued right after the group's last operands were consumed, its round trip under the result stores: +1.5 %)
     for (;; g += gstep) {
         if (dynamic) {
             int gi = 0;
@@ -666,6 +687,12 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             g = glo + __builtin_amdgcn_readfirstlane(gi);
         }
         if (g >= gend) break;
+        if (skipping) {                                     // groups of a class run that a launch with that class's stream in LDS serves
+            bool skip = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) skip |= r < D.nskip && g >= D.skip_lo[r] && g < D.skip_hi[r];
+            if (skip) continue;
+        }
         const int* __restrict__ grp = order + (size_t)g * GROUP;
         int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the step loop
 #pragma unroll

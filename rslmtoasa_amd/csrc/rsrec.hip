@@ -104,6 +104,7 @@ struct rsrec_handle {
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
+    long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
     long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
     int n_kubo_left_chunks = 0;
@@ -131,6 +132,11 @@ struct rsrec_handle {
         std::vector<int> level_max;     // per level: largest active-atom count over the chains of this entry
         std::vector<double> level_groups;   // [level][tau]: groups of 8 atoms (padding included) of operator class tau, summed over the chains
         std::vector<double> mult_hist;      // [pass 0/1][tau][nslots + 1]: block multiplications of the call by (pass, operator class, slot), summed over the chains
+        // the list of ALL atoms (used once a region covers the lattice) is sorted by operator class: one run of groups per class
+        struct ClassRun { int tau, lo, hi; };
+        std::vector<ClassRun> sat_runs;
+        std::vector<int> level_sat;         // per level: chains of this entry that use that list
+        int sat_base = 0;                   // its offset inside an order row
     };
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
@@ -139,6 +145,7 @@ struct rsrec_handle {
     const std::vector<int>* cur_level_max = nullptr;
     const std::vector<double>* cur_level_groups = nullptr;
     const std::vector<double>* cur_mult_hist = nullptr;
+    const RegionEntry* cur_entry = nullptr;
     int cur_nrows = 0;
     std::vector<unsigned> spatial_key;   // per atom: position along a space-filling curve (locality hint for the saturated order)
     // coefficients left on the device by the last recursion call: 0 = none, 1 = block Lanczos (d_coefA = a_b, d_coefB = b2_b or its root),
@@ -394,6 +401,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
+    else if (!strcmp(key, "s5_run_min")) h->opt_s5_run_min = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
 }
@@ -422,7 +430,7 @@ static void release_regions(rsrec_t* h) {
     if (!h->region_cache.empty()) (void)hipDeviceSynchronize();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->region_cache.clear();
-    h->cur_order = nullptr; h->cur_cum = nullptr;
+    h->cur_order = nullptr; h->cur_cum = nullptr; h->cur_entry = nullptr; h->cur_level_max = nullptr; h->cur_level_groups = nullptr; h->cur_mult_hist = nullptr;
 }
 
 extern "C" int rsrec_set_lattice(rsrec_t* h, int kk, int nncols, const int32_t* nn, const int32_t* iz, int nmax, int ntype) {
@@ -636,6 +644,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
             h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
             h->cur_mult_hist = &e->mult_hist;
+            h->cur_entry = e;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
@@ -748,6 +757,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         HIPCK(h, hipStreamSynchronize(h->stream));
         for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
         h->region_cache.clear();
+        h->cur_entry = nullptr;
     }
     auto* e = new rsrec_handle::RegionEntry();
     e->seeds.assign(seeds0, seeds0 + (size_t)nb * nseed);
@@ -768,6 +778,14 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         // groups by operator class: the saturated list is the same for every chain; a level-major list is walked once per chain
         std::vector<double> sat_hist(ntau_h, 0.0), run(ntau_h, 0.0);
         for (int g = 0; g < sat_count / GROUP; ++g) sat_hist[tau(sat_list[(size_t)g * GROUP])] += 1.0;
+        e->sat_base = cap;
+        e->level_sat.assign(nlev, 0);
+        if (grouped)
+            for (int g = 0; g < sat_count / GROUP; ++g) {
+                const int t = tau(sat_list[(size_t)g * GROUP]);
+                if (e->sat_runs.empty() || e->sat_runs.back().tau != t) e->sat_runs.push_back({t, g, g + 1});
+                else e->sat_runs.back().hi = g + 1;
+            }
         for (int c = 0; c < nb; ++c) {
             const int* orow = order.data() + (size_t)c * ostride;
             std::fill(run.begin(), run.end(), 0.0);
@@ -776,6 +794,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
                 const int cnt = cum[(size_t)c * nlev + l];
                 e->level_max[l] = std::max(e->level_max[l], cnt);
                 const bool sat = cum[(size_t)(nb + c) * nlev + l] != 0;
+                if (sat) e->level_sat[l] += 1;
                 if (!sat) for (; g < cnt / GROUP; ++g) run[grouped ? tau(orow[(size_t)g * GROUP]) : 0] += 1.0;
                 for (int t2 = 0; t2 < ntau_h; ++t2) e->level_groups[(size_t)l * ntau_h + t2] += sat ? sat_hist[t2] : run[t2];
             }
@@ -783,6 +802,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     }
     h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
     h->cur_mult_hist = &e->mult_hist;
+    h->cur_entry = e;
     return RSREC_OK;
 }
 
@@ -895,12 +915,12 @@ void s5_prepare(rsrec_t* h) {
     }
     (void)hipGetLastError();
 }
+// one launch: the LDS / persistent form for operator class `one` (>= 0) if it is wanted and fits, else the global-load form
 template <bool TWO>
-void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
-               const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0, S5Epilogue epi = S5Epilogue()) {
+void launch_s5_one(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
+                   const double* in, double* out, const double* in2, const double* extra, int ntau, S5Epilogue epi, int one) {
     const size_t lds_bytes = (size_t)op.ntr * S5_TRIPLE * sizeof(double);
-    const int one = op.single_class(set);
-    // s5_lds: 0 never, 1 (default) whenever the operator has one class of atoms and its stream fits, 2 the same
+    // s5_lds: 0 never, 1 (default) whenever the groups of the launch are of one class and its stream fits
     const bool want = h->opt_s5_lds >= 1;
     s5_prepare(h);
     const size_t lds_limit = h->s5_lds_limit;
@@ -925,6 +945,63 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, cons
         k_spmm5<TWO, true><<<g2, thr, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
         k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0, nullptr, 1, epi);
+}
+
+// k_spmm5 launch (CI vectors).  The operator fragments sit in LDS (one copy per persistent workgroup) when all groups a workgroup takes
+// run the same stream: operators with ONE class of atoms (a bulk crystal of one type).  Operators with several classes (surfaces,
+// compounds, impurity clusters) can take the same form per LARGE CLASS RUN of the class-sorted list of all atoms -- the list every chain
+// uses once its region covers the lattice: one persistent launch whose workgroup rows are dealt to the runs, plus one global-load launch
+// for what remains (small classes such as the per-atom blocks of an impurity region, chains whose regions are still growing) -- option
+// s5_lds = 2; by default they keep the global-load form, which is faster for them.  Per-chain stream heads (local-axis runs): global loads.
+template <bool TWO>
+void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, const int* cum, const int* iz, const Spmm5Operator& op, int set,
+               const double* in, double* out, const double* in2 = nullptr, const double* extra = nullptr, int ntau = 0, S5Epilogue epi = S5Epilogue()) {
+    SpmmDims SD = SD0;
+    const int one = op.single_class(set);
+    const rsrec_handle::RegionEntry* E = h->cur_entry;
+    // s5_lds = 2: the class-run form (measured slower than the global-load form on both multi-class workloads of bench.py -- fccCu001
+    // 5.58 vs 5.25 ms per launch, and the launch-per-run variant B2FeCo 3.07 vs 2.36 ms: the runs cannot balance against each other --
+    // so it is not the default; the parity tests run it)
+    const bool multi = one < 0 && h->opt_s5_lds >= 2 && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.level >= 0 && SD.level < (int)E->level_sat.size() &&
+                       E->level_sat[SD.level] > 0 && op.ntau == h->nmax + h->ntype && (grid.x >= (unsigned)std::max(16, h->n_cu / 16 * 16) || h->opt_s5_queue >= 2) && (size_t)op.ntr * S5_TRIPLE * sizeof(double) <= (s5_prepare(h), h->s5_lds_limit);
+    if (!multi) launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, extra, ntau, epi, one);
+    else {
+        // class runs worth workgroups of their own: at least two groups per workgroup of a full persistent launch over the chains on the list
+        SD.sat_base = E->sat_base;
+        const long min_groups = h->opt_s5_run_min > 0 ? h->opt_s5_run_min : std::max<long>(64, 2L * h->n_cu * 8 / std::max(1, E->level_sat[SD.level]));
+        const int spin_by_xcd = op.spin_mixing ? 0 : 1;
+        const int row = spin_by_xcd ? 8 : 16;
+        const int ncu = std::max(16, h->n_cu / 16 * 16), total_rows = ncu / row;
+        SpmmDims SR = SD;
+        long sum_groups = 0;
+        for (const auto& R : E->sat_runs) {
+            if (SR.nruns == 4 || R.hi - R.lo < min_groups || op.ksteps[(size_t)set * op.ntau + R.tau] == 0) continue;
+            SR.run_tau[SR.nruns] = R.tau; SR.run_glo[SR.nruns] = R.lo; SR.run_ghi[SR.nruns] = R.hi; ++SR.nruns;
+            sum_groups += R.hi - R.lo;
+        }
+        const size_t qbytes = (size_t)4 * SD.nchains * 16 * sizeof(int);
+        const bool can = SR.nruns > 0 && SR.nruns <= total_rows && (h->opt_s5_queue >= 1) && (!h->capturing || h->d_s5queue.bytes >= qbytes) &&
+                         h->d_s5queue.reserve(qbytes) == hipSuccess && hipMemsetAsync(h->d_s5queue.p, 0, qbytes, h->stream) == hipSuccess;
+        if (can) {
+            // ONE persistent launch: the workgroup rows are dealt to the runs in proportion to their groups (at least one row each), every
+            // run with its own counters; the launch-per-run form paid one tail per run (measured: B2FeCo 22 %, fccCu001 5 % slower)
+            int left = total_rows - SR.nruns, acc = 0;
+            for (int r = 0; r < SR.nruns; ++r) {
+                const long gr = SR.run_ghi[r] - SR.run_glo[r];
+                int extra_rows = r == SR.nruns - 1 ? left : (int)std::min<long>(left, (gr * (total_rows - SR.nruns) + sum_groups / 2) / std::max(1L, sum_groups));
+                left -= extra_rows;
+                SR.run_row0[r] = acc;
+                acc += 1 + extra_rows;
+            }
+            SR.run_row0[SR.nruns] = acc;
+            const size_t lds_bytes = (size_t)op.ntr * S5_TRIPLE * sizeof(double);
+            k_spmm5<TWO, true><<<dim3(ncu, 1), S5_WG_GROUPS * 128, lds_bytes, h->stream>>>(SR, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau,
+                                                                                          0, h->d_s5queue.as<int>(), spin_by_xcd, epi);
+            for (int r = 0; r < SR.nruns; ++r) { SD.skip_lo[r] = SR.run_glo[r]; SD.skip_hi[r] = SR.run_ghi[r]; }
+            SD.nskip = SR.nruns;
+        }
+        launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, nullptr, ntau, epi, -1);
+    }
     if (h->cur_level_groups && SD.level >= 0 && (size_t)(SD.level + 1) * op.ntau <= h->cur_level_groups->size() && SD.cpo == 1 && op.ntau == h->nmax + h->ntype)
         for (int t = 0; t < op.ntau; ++t) h->n_hop_mfma_flop += (*h->cur_level_groups)[(size_t)SD.level * op.ntau + t] * op.flops_per_group(set, t);
 }
@@ -1183,7 +1260,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->s4_op.frag_set(0), (uintptr_t)h->s4_op.meta_set(0), (uintptr_t)h->d_nbr.p, (uintptr_t)h->d_nbr5.p, (uintptr_t)h->d_iz.p,
                                           (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
                                           (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
-                                          (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue,
+                                          (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
                                           (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing};
             for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
             if (!h->graph_exec || key != h->graph_key) {

@@ -93,7 +93,9 @@ def test_whole_vector_product_on_random_ragged_lattice(kk, nslots, ntype, nmax, 
     rng = np.random.default_rng(1000 * kk + 10 * nslots + ntype + 2 * int(hoh) + int(collinear))
     p = random_problem(rng, kk, nslots, ntype, nmax, hoh, collinear)
     rec = Recursion(*objects_from(p, np.array([1], np.int32), 4), device=0)
-    rec.set_option("s5_queue", 2)    # single-class operators (operator stream in LDS): persistent workgroups with a group queue
+    rec.set_option("s5_queue", 2)    # operator stream in LDS: persistent workgroups with a group queue
+    rec.set_option("s5_lds", 2)      # several classes of atoms: the class-run form (workgroup rows dealt to the runs of the class-sorted atom list)
+    rec.set_option("s5_run_min", 1)  # ... for runs of any size
     x = np.asfortranarray(rng.standard_normal((18, 18, kk)) + 1j * rng.standard_normal((18, 18, kk)))
     a, b = 1.7, -0.3
     want = ham_vec_numpy(p, x, a, b)
@@ -117,7 +119,7 @@ RECUR_CASES = [  # kk, nslots, ntype, nmax, hoh, collinear
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, "ci"])
+@pytest.mark.parametrize("variant", [1, 2, "ci", "runs"])
 @pytest.mark.parametrize("kk,nslots,ntype,nmax,hoh,collinear", RECUR_CASES)
 def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, collinear, variant, oracle_lib):
     """Block Lanczos and Chebyshev moments on the same random lattices (region growth through missing neighbours and impurity atoms)
@@ -128,9 +130,16 @@ def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, colli
     irec = np.array([1, kk // 2, kk], np.int32)          # an impurity atom (if any), a bulk atom, the last atom
     lld = 6
     rec = Recursion(*objects_from(p, irec, lld, emin=-60.0, emax=60.0), device=0)
-    if variant == "ci":
+    if variant in ("ci", "runs"):
         rec.set_option("kernels", 2)
         rec.set_option("spmm5", 2)
+        if variant == "runs":
+            # operators with several classes of atoms: once a chain's region covers the lattice every class run of the class-sorted atom
+            # list gets a launch with that class's operator stream in LDS (forced here for runs of any size, persistent queue form
+            # included), the rest -- impurity atoms, chains still growing -- the global-load launch
+            rec.set_option("s5_lds", 2)
+            rec.set_option("s5_run_min", 1)
+            rec.set_option("s5_queue", 2)
     else:
         rec.set_option("kernels", variant)
         rec.set_option("spmm5", 1)
