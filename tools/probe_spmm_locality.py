@@ -49,3 +49,13 @@ if __name__ == "__main__":
         nn[:, s] = np.minimum(base + (s % 8), kk - 1) + 1
     q["nn"] = nn
     run(q, seeds, coefs, lld, nch, "clique-of-8 (all cache hits)")
+    # neighbours at index distance +-(8 m + 1), m = 1..7: 120 distinct blocks per group like the real lattice, but every block is used by atoms
+    # within a window of 224 consecutive atoms: the gathers miss L1 and hit L2 (no fabric traffic beyond the compulsory 1x)
+    r = dict(p)
+    nn = p["nn"].copy()
+    idx = np.arange(kk)
+    for s in range(1, 15):
+        d = (8 * ((s + 1) // 2) + 1) * (1 if s % 2 else -1)      # 9, -9, 17, -17, ...: connects all residues mod 8
+        nn[:, s] = (idx + d) % kk + 1
+    r["nn"] = nn
+    run(r, seeds, coefs, lld, nch, "index-near neighbours (L2 hits)")

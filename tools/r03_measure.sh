@@ -3,7 +3,7 @@
 # usage: tools/r03_measure.sh <tag> [what...]   what in: tests default c3 hoh cheb mix fcc imp sq   (default: all but tests)
 set -e
 TAG=${1:-r03}; shift || true
-WHAT=${*:-default c3 hoh cheb mix fcc imp sq}
+WHAT=${*:-default c3 hoh cheb mix fcc imp kubo sq}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
@@ -18,7 +18,7 @@ run_bench() { # name args...
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r=d["roofline"]
-print("   %s: %.1f TFLOP/s  %.1f ms/step  %.1f sites/s  frac_kernel %.3f (algorithmic %.3f, executed %.3f) frac_step %.3f (algorithmic %.3f) hop %.3f ms  cpu %s" % (d["config"]["workload_key"], d["value"]*1e-3, d["ms_per_step"], d["sites_per_s"], r["frac_kernel"], r["frac_algorithmic"], r.get("executed",{}).get("frac",0), r["frac_step"], r["frac_step_algorithmic"], r["avg_launch_ms"], d.get("cpu_baseline",{}).get("value")))
+print("   %s: %.1f TFLOP/s  %.1f ms/step  %.1f sites/s  frac_kernel %.3f (algorithmic %.3f, executed %.3f) frac_step %.3f (algorithmic %.3f) hop %.3f ms  cpu %s" % (d["config"]["workload_key"], d["value"]*1e-3, d["ms_per_step"], d.get("sites_per_s", d.get("vectors_per_s", 0.0)), r["frac_kernel"], r["frac_algorithmic"], r.get("executed",{}).get("frac",0), r["frac_step"], r["frac_step_algorithmic"], r["avg_launch_ms"], d.get("cpu_baseline",{}).get("value")))
 PY
 }
 prof() { # tag key extra...
@@ -32,5 +32,6 @@ if has cheb; then run_bench cheb --recur chebyshev --steps 3 --warmup 1; prof ch
 if has mix; then run_bench mix --spin-mixing --steps 3 --warmup 1; prof mix block_mix_c22_s64_l50 --spin-mixing; fi
 if has fcc; then run_bench fcc --workload fccCu001 --steps 3 --warmup 1; prof fcc chebyshev_fccCu001_s64_l50 --workload fccCu001; fi
 if has imp; then run_bench imp --workload B2FeCo --steps 3 --warmup 1; prof imp block_hoh_B2FeCo_s64_l50 --workload B2FeCo; fi
+if has kubo; then run_bench kubo50 --workload kubo --cond-ll 50 --steps 3 --warmup 1; run_bench kubo500 --workload kubo --cond-ll 500 --steps 1 --warmup 1; prof kubo kubo_c20_l50 --workload kubo --cond-ll 50; fi
 if has sq; then tools/pmc_sq.sh ${TAG}_c2 > $O/sq_c2.txt 2>&1 || { tail $O/sq_c2.txt; exit 1; }; tools/pmc_sq.sh ${TAG}_mix --spin-mixing > $O/sq_mix.txt 2>&1 || { tail $O/sq_mix.txt; exit 1; }; fi
 echo done
