@@ -128,6 +128,9 @@ __device__ __forceinline__ void gram_block_out(const GramAcc& A, double* lds /*[
     }
 }
 
+#ifndef ADOT_UNROLL
+#define ADOT_UNROLL 4
+#endif
 // ---- A_n partial: Gm = sum_rows psihat^T * that   (hop_b :1642) -------------------------------------------------------
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, int level, int zero_block, const double* __restrict__ psi,
                                                                const double* __restrict__ tvec, double* partial /*[chain][nblk][1296]*/) {
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
     const int nbx = active_workgroups(ngroups);
     for (GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
-#pragma unroll 4
+#pragma unroll ADOT_UNROLL
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);               // k-row of this lane
             const double p0 = ps[rk.off + l15], p1 = ps[rk.off + 16 + l15], pr = ps[rk.off + 32 + l3];

@@ -404,6 +404,9 @@ __global__ void k_uscheme_init(double2* Bmats, double* tabs, int ci) {
 // ======================================================================================================================
 // FUSED: the element-wise step was done by the SpMM's epilogue (S5Epilogue): `out_all` already holds the new vector, only the Gram
 // matrices are formed here, in one pass over cur and out.
+#ifndef CHEB_UNROLL
+#define CHEB_UNROLL 4      // four k-steps of 4 stacked rows in flight (2: 1.31 ms per launch at 64 x 22^3, 4: 1.07 ms; 6: no further gain)
+#endif
 template <bool FIRST, bool FUSED = false>
 __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                const double* __restrict__ cur_all, const double* __restrict__ old_all,
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_cheb(ChainView CV, in
     const int nbx = active_workgroups(ngroups);
     for (GroupWalk w((int)blockIdx.x < nbx ? ngroups : 0, wave, nbx); w.g < w.end; w.g += w.step) {
         const int* grp = order + (size_t)w.g * GROUP;
-#pragma unroll 2
+#pragma unroll CHEB_UNROLL
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);
             const double c0 = cu[rk.off + l15], c1 = cu[rk.off + 16 + l15], cr = cu[rk.off + 32 + l3];
