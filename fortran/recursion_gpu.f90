@@ -70,7 +70,7 @@ contains
    !> Same construction as recursion.f90:132-143 (pointers + restore_to_default); no device state is created here.
    function gpu_constructor(hamiltonian_obj, energy_obj) result(obj)
       type(recursion_gpu) :: obj
-      type(hamiltonian), target, intent(in) :: hamiltonian_obj
+      class(hamiltonian), target, intent(in) :: hamiltonian_obj     ! (class: a type(hamiltonian_gpu) is accepted as well)
       type(energy), target, intent(in) :: energy_obj
 
       obj%hamiltonian => hamiltonian_obj
@@ -308,6 +308,7 @@ contains
       class(recursion_gpu), intent(inout) :: this
       integer :: na
       integer(c_int) :: rc
+      type(c_ptr) :: ctx
       complex(rp), allocatable, target :: buf(:, :, :, :)
 
       if (this%lattice%njij == 0) then
@@ -316,7 +317,7 @@ contains
          na = atoms_per_process*4
       end if
       if (na <= 0) return
-      call sync_device(this, .false.)
+      ctx = rsrec_gpu_context()                                  ! (the square roots read no lattice or operator table: nothing to send)
       allocate (buf(18, 18, this%lattice%control%lld, na))
       buf = this%b2_b(:, :, 1:this%lattice%control%lld, 1:na)
       rc = rsrec_zsqr(g_handle, int(this%lattice%control%lld*na, c_int), c_loc(buf))

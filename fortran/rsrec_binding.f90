@@ -81,6 +81,15 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_assemble_blocks(handle, part, ncls, nslots, hoh, hmag, nbr_type, obarm, ntype, blocks, blocks_o) &
+         bind(C, name='rsrec_assemble_blocks') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: part, ncls, nslots, hoh, ntype
+         type(c_ptr), value :: hmag, nbr_type, obarm, blocks, blocks_o
+         integer(c_int) :: rc
+      end function
+
       function rsrec_block_lanczos(handle, nsites, seed_atoms, lld, a_b, b2_b) bind(C, name='rsrec_block_lanczos') result(rc)
          import :: c_int, c_ptr
          type(c_ptr), value :: handle

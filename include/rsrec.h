@@ -71,6 +71,19 @@ int rsrec_set_positions(rsrec_t *h, const double *cr);
 int rsrec_set_hamiltonian(rsrec_t *h, int nslots, int hoh, int nsp, const double *ee, const double *lsham,
                           const double *eeo, const double *enim, const double *hall, const double *hallo);
 
+/* The raw blocks themselves, assembled on the device: what build_bulkham (hamiltonian.f90:1553-1616; part = 0: one class per atom type,
+ * result ee / eeo) and build_locham (:1618-1667; part = 1: one class per impurity atom, result hall / hallo) do after chbar_nc:
+ *   blocks(:,:,m,c)   = [[H0 + Hz, Hx - i Hy], [Hx + i Hy, H0 - Hz]]  with (Hx, Hy, Hz, H0) = hmag(:,:,m,1..4) of class c   (:1565-1570, :1631-1636)
+ *   blocks_o(:,:,m,c) = blocks(:,:,m,c) * obarm(:,:,nbr_type(m,c)),  zero where nbr_type(m,c) = 0                          (:1599, :1654; hoh only)
+ *   hmag     : complex (9,9,nslots,4,ncls) -- the scratch array chbar_nc fills, collected per class by the caller
+ *   nbr_type : int32 (nslots,ncls), atom type (1..ntype) behind slot m of the class atom (slot 1: the atom itself), 0 = no atom (:1586-1597)
+ *   obarm    : complex (18,18,ntype) (build_obarm, hamiltonian.f90:1486-1506);  nbr_type / obarm / blocks_o may be NULL when hoh = 0
+ *   blocks, blocks_o : complex (18,18,nslots,ncls) out -- the caller's ee / eeo or hall / hallo (the reference's host routines read them too).
+ * The device copies stay behind: a following rsrec_set_hamiltonian that is handed exactly these arrays (compared bit for bit) takes them
+ * from there instead of uploading; arrays that were edited on the host in between are uploaded as always.  Needs no lattice. */
+int rsrec_assemble_blocks(rsrec_t *h, int part, int ncls, int nslots, int hoh, const double *hmag, const int32_t *nbr_type,
+                          const double *obarm, int ntype, double *blocks, double *blocks_o);
+
 /* Block Lanczos recursion for `nsites` independent chains seeded with psi(:,:,seed) = I18.
  * Replaces recur_b (recursion.f90:1807-1866) + crecal_b (:1873-1973) + hop_b/hop_b_hoh (:1560/:1411).
  *   seed_atoms : int32 (nsites), 1-based cluster atom numbers (lattice%irec(start_atom:end_atom))
@@ -257,6 +270,7 @@ int rsrec_set_option(rsrec_t *h, const char *key, long value);
  *   out[9] flops of the H|psi> applications that the operator's BLOCK STRUCTURE requires: out[4] counts the reference's zgemm on full
  *          18x18 blocks (46 656 flop each, recursion.f90:1618); a spin-diagonal block (every hopping block of a collinear magnet,
  *          hamiltonian.f90:1553-1617) needs 23 328, a spin-mixing block 46 656 -- the unit roofline fractions are quoted in.
+ *   out[10] block arrays (0..4: ee, eeo, hall, hallo) the last rsrec_set_hamiltonian took from rsrec_assemble_blocks' device copies.
  * After rsrec_block_green: out[0] = kernel + transfers, out[1] = the Green kernel alone. */
 int rsrec_get_timing(rsrec_t *h, double *out, int n);
 

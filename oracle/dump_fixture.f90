@@ -49,7 +49,7 @@ program dump_fixture
    complex(rp), allocatable :: g_ef(:, :, :)
    integer :: ia, u, kind_rec, nslots, hoh_i, nsites, ncheb
    real(rp) :: acheb, bcheb
-   character(len=32) :: pre
+   character(len=32) :: pre, envbuf
 
    rank = 0
    numprocs = 1
@@ -215,9 +215,53 @@ program dump_fixture
    !      blocks the rotation starts from, the moment directions and the rotation matrices ROTMAT(car2sph(mom)) (math.f90:2026)
    !      go to a side file.
    if (hamiltonian_obj%local_axis) call dump_local_axis()
+   call get_environment_variable('RSREC_DUMP_HMAG', envbuf)
+   if (len_trim(envbuf) > 0 .and. .not. hamiltonian_obj%local_axis) call dump_hmag()
    write (*, *) 'dump_fixture: wrote fixture.bin kk=', lattice_obj%kk, ' nmax=', lattice_obj%nmax, ' nrec=', lattice_obj%nrec, &
       ' lld=', control_obj%lld, ' nslots=', nslots, ' kind=', kind_rec, ' hoh=', hoh_i
 contains
+   ! ---- the INPUTS of build_bulkham / build_locham (hamiltonian.f90:1553-1667): the four 9x9 parts (Hx, Hy, Hz, H0) that chbar_nc
+   !      leaves in hmag for every class atom, the type behind every neighbour slot, and obarm -- what a device-side assembly of
+   !      ee / eeo / hall / hallo starts from (SURVEY 8 f2).  Their outputs are the blocks already in fixture.bin.
+   subroutine dump_hmag()
+      integer :: v, nt, ia_c, ino, nr, m, ja, nsl
+      integer, allocatable :: ji(:)
+      nsl = size(hamiltonian_obj%ee, 3)
+      allocate (ji(nsl))
+      open (newunit=v, file='hmag.bin', access='stream', form='unformatted', status='replace')
+      write (v) int(z'484d4731'), lattice_obj%ntype, lattice_obj%nmax, nsl, hoh_i
+      do nt = 1, lattice_obj%ntype
+         ia_c = lattice_obj%atlist(nt)
+         call one_class(ia_c, nt)
+      end do
+      if (control_obj%calctype == 'I') then
+         do nt = 1, lattice_obj%nmax
+            call one_class(nt, nt)
+         end do
+      end if
+      write (v) hamiltonian_obj%obarm
+      close (v)
+   contains
+      subroutine one_class(iatom, iclass)
+         integer, intent(in) :: iatom, iclass
+         ino = lattice_obj%num(iatom)
+         nr = lattice_obj%nn(iatom, 1)
+         call hamiltonian_obj%chbar_nc(iatom, nr, ino, iclass)
+         ji = 0
+         do m = 1, nr
+            if (m == 1) then
+               ji(m) = lattice_obj%iz(iatom)
+            else
+               ja = lattice_obj%nn(iatom, m)
+               if (ja /= 0) ji(m) = lattice_obj%iz(ja)
+            end if
+         end do
+         write (v) nr
+         write (v) ji
+         write (v) hamiltonian_obj%hmag(:, :, 1:nsl, 1:4)
+      end subroutine one_class
+   end subroutine dump_hmag
+
    subroutine dump_local_axis()
       use math_mod, only: car2sph, ROTMAT
       integer :: v, is

@@ -394,6 +394,54 @@ def run_orbital_case(name):
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+HMAG_CASES = ["bccFe_nsp2_block_hoh", "bccFe_nsp4_block", "fccCu001_block_hoh", "B2FeCo_block_hoh"]
+
+
+def run_hmag_case(name):
+    """<name>_hmag.npz: the INPUTS of the reference's build_bulkham / build_locham (hamiltonian.f90:1553-1667) for the run of <name>.npz:
+    the four 9x9 parts chbar_nc leaves in `hmag` per class atom, the atom type behind every neighbour slot, `obarm`.  The outputs they
+    pin are the ee / eeo / hall / hallo arrays of <name>.npz (checked here to be the same run)."""
+    import struct
+    case_dir, patch = CASES[name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_hm_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        q = os.path.join(scratch, "input.nml")
+        txt = patch_namelist(open(q).read(), patch)
+        open(q, "w").write(txt)
+        r = run_with_unlimited_stack([os.path.join(HERE, "_ref", "dump_fixture.x")], cwd=scratch, env={"OMP_NUM_THREADS": "8", "RSREC_DUMP_HMAG": "1"})
+        if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "hmag.bin")):
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_fixture (hmag) failed for " + name)
+        d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
+        base = fio.load_golden(os.path.join(GOLD, name + ".npz"))
+        for k in ("ee", "eeo", "hall", "hallo"):
+            if k in base:
+                assert np.array_equal(base[k], d[k]), "%s of this run differs from %s.npz" % (k, name)
+        with open(os.path.join(scratch, "hmag.bin"), "rb") as f:
+            magic, ntype, nmax, nsl, hoh = struct.unpack("<5i", f.read(20))
+            assert magic == 0x484d4731 and ntype == d["ntype"] and nsl == d["ee"].shape[2]
+            ncls = ntype + (nmax if d["nmax"] > 0 else 0)
+            nr, ji, hm = [], [], []
+            for _ in range(ncls):
+                nr.append(struct.unpack("<i", f.read(4))[0])
+                ji.append(fio._rd(f, np.int32, (nsl,)))
+                hm.append(fio._rd(f, np.complex128, (9, 9, nsl, 4)))
+            obarm = fio._rd(f, np.complex128, (18, 18, ntype))
+            assert f.read(1) == b""
+        out = {"hmag_type": np.stack(hm[:ntype], axis=4), "nbr_type_type": np.stack(ji[:ntype], axis=1), "nr_type": np.array(nr[:ntype], np.int32),
+               "obarm": obarm, "hoh": np.array(hoh), "source_case": np.array(case_dir), "namelist_patch": np.array(repr(patch))}
+        if ncls > ntype:
+            out.update(hmag_atom=np.stack(hm[ntype:], axis=4), nbr_type_atom=np.stack(ji[ntype:], axis=1), nr_atom=np.array(nr[ntype:], np.int32))
+        np.savez_compressed(os.path.join(GOLD, name + "_hmag.npz"), **out)
+        print("%-24s ntype=%d nmax=%d nslots=%d -> %.1f KB" % (name + "_hmag", ntype, nmax if ncls > ntype else 0, nsl, os.path.getsize(os.path.join(GOLD, name + "_hmag.npz")) / 1024))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def spread_case(name, threads=(1, 2, 8)):
     """<name>_spread.npz: the compiled reference's OWN run-to-run spread on a supercell case -- the same ref_kernel.x run at
     several OpenMP thread counts (its reductions are `omp reduction` sums, recursion.f90:1638-1645: the summation order depends
@@ -416,13 +464,15 @@ def spread_case(name, threads=(1, 2, 8)):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES)
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES) + [c + "_hmag" for c in HMAG_CASES]
                             + ["sc_4x4x8_block_spread", "sc_4x4x8_block_hoh_spread"])
     for n in want:
         if n in KUBO_CASES:
             run_kubo_case(n)
         elif n in ORBITAL_CASES:
             run_orbital_case(n)
+        elif n.endswith("_hmag"):
+            run_hmag_case(n[:-len("_hmag")])
         elif n.endswith("_spread"):
             spread_case(n[:-len("_spread")])
         elif n.endswith("_green"):

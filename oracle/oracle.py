@@ -204,3 +204,25 @@ def site_partition(rank, nprocs, nsites):
     s, e = C.c_int(), C.c_int()
     lib().orc_site_partition(rank, nprocs, nsites, C.byref(s), C.byref(e))
     return s.value, e.value
+
+
+def assemble_blocks(hmag, nbr_type=None, obarm=None):
+    """build_bulkham / build_locham after chbar_nc (hamiltonian.f90:1565-1570, :1599 / :1631-1636, :1654), restated with numpy (checker only):
+    blocks = [[H0 + Hz, Hx - i Hy], [Hx + i Hy, H0 - Hz]] from hmag (9,9,nslots,4,ncls) = (Hx, Hy, Hz, H0); blocks_o = blocks . obarm(type
+    behind the slot), zero for empty slots.  Pinned by tests/golden/*_hmag.npz against the reference's own ee / eeo / hall / hallo."""
+    hm = np.asarray(hmag)
+    nsl, ncls = hm.shape[2], hm.shape[4]
+    b = np.zeros((18, 18, nsl, ncls), np.complex128, order="F")
+    b[:9, :9] = hm[:, :, :, 3] + hm[:, :, :, 2]
+    b[9:, 9:] = hm[:, :, :, 3] - hm[:, :, :, 2]
+    b[:9, 9:] = hm[:, :, :, 0] - 1j * hm[:, :, :, 1]
+    b[9:, :9] = hm[:, :, :, 0] + 1j * hm[:, :, :, 1]
+    if obarm is None:
+        return b, None
+    bo = np.zeros_like(b)
+    for c in range(ncls):
+        for m in range(nsl):
+            t = int(nbr_type[m, c])
+            if t > 0:
+                bo[:, :, m, c] = b[:, :, m, c] @ obarm[:, :, t - 1]
+    return b, bo

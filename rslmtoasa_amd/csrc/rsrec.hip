@@ -35,6 +35,7 @@
 #include "kernels_green.hpp"
 #include "kernels_ldos.hpp"
 #include "kernels_kubo.hpp"
+#include "kernels_assemble.hpp"
 #include <dlfcn.h>
 
 using namespace rsrec;
@@ -90,6 +91,12 @@ struct rsrec_handle {
     size_t term_attr_lds = 0;
     std::vector<double> host_ee, host_lsham, host_eeo, host_enim, host_hall, host_hallo;   // operator arrays as last set (Kubo operator tables; local-axis runs)
     std::vector<double> host_st, host_loc;   // ee / hall with l.s folded into the on-site block when !hoh (what d_hst / d_hloc hold)
+    // raw blocks assembled on the device (rsrec_assemble_blocks): [part: 0 per-type, 1 per-atom][0: blocks, 1: blocks x obar]; asm_host = what the
+    // caller got back -- rsrec_set_hamiltonian recognises those arrays bitwise and then takes the device copies instead of uploading
+    DevBuf d_asm[2][2], d_asm_in;
+    std::vector<double> asm_host[2][2];
+    int asm_nslots[2] = {0, 0}, asm_ncls[2] = {0, 0}, asm_hoh[2] = {0, 0};
+    int n_asm_reused = 0;        // block arrays the last rsrec_set_hamiltonian took from those device copies (0..4)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
@@ -408,9 +415,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
 
 extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
     if (!h || !out) return RSREC_ERR_ARG;
-    const double v[10] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop,
-                          h->n_req_flop};
-    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+    const double v[11] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop,
+                          h->n_req_flop, (double)h->n_asm_reused};
+    for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
     return RSREC_OK;
 }
 
@@ -551,29 +558,46 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
     if (!hoh)
         for (int t = 0; t < ntype; ++t)
             for (size_t e = 0; e < B; ++e) st[B * nslots * t + e] += lsham[B * t + e];
-    HIPCK(h, h->d_hst.reserve(st.size() * 8));
-    HIPCK(h, hipMemcpy(h->d_hst.p, st.data(), st.size() * 8, hipMemcpyHostToDevice));
+    // Arrays that rsrec_assemble_blocks produced (the caller hands back, bit for bit, what it was given) are already on the device:
+    // a device-to-device copy (+ the l.s fold) replaces the upload.  Anything else -- arrays built on the host, or edited since -- is uploaded.
+    h->n_asm_reused = 0;
+    auto resident = [&](int part, int which, const double* arr, int ncls) -> const double* {
+        const size_t n = B * nslots * ncls;
+        if (!arr || h->asm_nslots[part] != nslots || h->asm_ncls[part] != ncls || h->asm_host[part][which].size() != n) return nullptr;
+        if (std::memcmp(arr, h->asm_host[part][which].data(), n * 8) != 0) return nullptr;
+        h->n_asm_reused++;
+        return h->d_asm[part][which].as<double>();
+    };
+    auto place = [&](DevBuf& dst, const double* dev_src, const double* host_src, size_t n) -> hipError_t {
+        hipError_t e = dst.reserve(n * 8);
+        if (e != hipSuccess) return e;
+        if (dev_src) return hipMemcpyAsync(dst.p, dev_src, n * 8, hipMemcpyDeviceToDevice, h->stream);
+        return hipMemcpy(dst.p, host_src, n * 8, hipMemcpyHostToDevice);
+    };
+    HIPCK(h, h->d_lsham.reserve(B * ntype * 8));
+    HIPCK(h, hipMemcpy(h->d_lsham.p, lsham, B * ntype * 8, hipMemcpyHostToDevice));
+    {
+        const double* dev = resident(0, 0, ee, ntype);
+        HIPCK(h, place(h->d_hst, dev, st.data(), st.size()));
+        if (dev && !hoh) k_fold_onsite<<<ntype, 324, 0, h->stream>>>(h->d_hst.as<double2>(), nslots, h->d_lsham.as<double2>(), nullptr);
+    }
     std::vector<double> loc;
     if (nmax > 0) {
         loc.assign(hall, hall + B * nslots * nmax);
         if (!hoh)
             for (int i = 0; i < nmax; ++i)
                 for (size_t e = 0; e < B; ++e) loc[B * nslots * i + e] += lsham[B * h->iz0[i] + e];   // :1582
-        HIPCK(h, h->d_hloc.reserve(loc.size() * 8));
-        HIPCK(h, hipMemcpy(h->d_hloc.p, loc.data(), loc.size() * 8, hipMemcpyHostToDevice));
+        const double* dev = resident(1, 0, hall, nmax);
+        HIPCK(h, place(h->d_hloc, dev, loc.data(), loc.size()));
+        if (dev && !hoh) k_fold_onsite<<<nmax, 324, 0, h->stream>>>(h->d_hloc.as<double2>(), nslots, h->d_lsham.as<double2>(), h->d_iz.as<int>());
     }
-    HIPCK(h, h->d_lsham.reserve(B * ntype * 8));
-    HIPCK(h, hipMemcpy(h->d_lsham.p, lsham, B * ntype * 8, hipMemcpyHostToDevice));
     if (hoh) {
-        HIPCK(h, h->d_host.reserve(B * nslots * ntype * 8));
-        HIPCK(h, hipMemcpy(h->d_host.p, eeo, B * nslots * ntype * 8, hipMemcpyHostToDevice));
+        HIPCK(h, place(h->d_host, resident(0, 1, eeo, ntype), eeo, B * nslots * ntype));
         HIPCK(h, h->d_enim.reserve(B * ntype * 8));
         HIPCK(h, hipMemcpy(h->d_enim.p, enim, B * ntype * 8, hipMemcpyHostToDevice));
-        if (nmax > 0) {
-            HIPCK(h, h->d_holoc.reserve(B * nslots * nmax * 8));
-            HIPCK(h, hipMemcpy(h->d_holoc.p, hallo, B * nslots * nmax * 8, hipMemcpyHostToDevice));
-        }
+        if (nmax > 0) HIPCK(h, place(h->d_holoc, resident(1, 1, hallo, nmax), hallo, B * nslots * nmax));
     }
+    HIPCK(h, hipGetLastError());
     // MFMA-fragment form of the same operator tables.  k_spmm5's streams are assembled on the DEVICE from the raw blocks uploaded above
     // (Spmm5Operator::build -> k_s5_emit; option s5_host_emit = 1: on the host, the round-2 path, kept as the cross-check).  k_spmm4's
     // tables (small launches of the plain operator only) are built when a call first needs them (ensure_s4).
@@ -590,6 +614,36 @@ extern "C" int rsrec_set_hamiltonian(rsrec_t* h, int nslots, int hoh, int nsp, c
         }
     }
     h->have_ham = true;
+    return RSREC_OK;
+}
+
+extern "C" int rsrec_assemble_blocks(rsrec_t* h, int part, int ncls, int nslots, int hoh, const double* hmag, const int32_t* nbr_type, const double* obarm, int ntype,
+                                     double* blocks, double* blocks_o) {
+    if (!h) return RSREC_ERR_ARG;
+    if (part < 0 || part > 1 || ncls < 1 || nslots < 1 || !hmag || !blocks) return fail(h, RSREC_ERR_ARG, "rsrec_assemble_blocks: part=%d ncls=%d nslots=%d or a missing array", part, ncls, nslots);
+    if (hoh && (!nbr_type || !obarm || !blocks_o || ntype < 1)) return fail(h, RSREC_ERR_ARG, "rsrec_assemble_blocks: hoh needs nbr_type, obarm (ntype=%d) and blocks_o", ntype);
+    if (hoh)
+        for (size_t q = 0; q < (size_t)ncls * nslots; ++q)
+            if (nbr_type[q] < 0 || nbr_type[q] > ntype) return fail(h, RSREC_ERR_ARG, "rsrec_assemble_blocks: nbr_type[%zu]=%d outside 0..%d", q, nbr_type[q], ntype);
+    HIPCK(h, hipSetDevice(h->device));
+    h->asm_nslots[part] = h->asm_ncls[part] = 0;          // nothing valid while this runs
+    const size_t nblk = (size_t)ncls * nslots, hm_bytes = nblk * 4 * 81 * 16, ty_bytes = nblk * 4, ob_bytes = hoh ? (size_t)ntype * 324 * 16 : 0;
+    const size_t ty_off = (hm_bytes + 255) / 256 * 256, ob_off = ty_off + (ty_bytes + 255) / 256 * 256;
+    HIPCK(h, h->d_asm_in.reserve(ob_off + ob_bytes + 256));
+    char* in = h->d_asm_in.as<char>();
+    XFER(xfer_h2d(h, in, hmag, hm_bytes));
+    if (hoh) { XFER(xfer_h2d(h, in + ty_off, nbr_type, ty_bytes)); XFER(xfer_h2d(h, in + ob_off, obarm, ob_bytes)); }
+    HIPCK(h, h->d_asm[part][0].reserve(nblk * 324 * 16));
+    if (hoh) HIPCK(h, h->d_asm[part][1].reserve(nblk * 324 * 16));
+    k_assemble_blocks<<<dim3(nslots, ncls), 384, 0, h->stream>>>(reinterpret_cast<const double2*>(in), reinterpret_cast<const int*>(in + ty_off),
+                                                                 reinterpret_cast<const double2*>(in + ob_off), nslots, hoh ? 1 : 0, h->d_asm[part][0].as<double2>(),
+                                                                 hoh ? h->d_asm[part][1].as<double2>() : nullptr);
+    HIPCK(h, hipGetLastError());
+    XFER(xfer_d2h(h, blocks, h->d_asm[part][0].p, nblk * 324 * 16));
+    if (hoh) XFER(xfer_d2h(h, blocks_o, h->d_asm[part][1].p, nblk * 324 * 16));
+    h->asm_host[part][0].assign(blocks, blocks + nblk * 648);
+    if (hoh) h->asm_host[part][1].assign(blocks_o, blocks_o + nblk * 648); else h->asm_host[part][1].clear();
+    h->asm_nslots[part] = nslots; h->asm_ncls[part] = ncls; h->asm_hoh[part] = hoh ? 1 : 0;
     return RSREC_OK;
 }
 

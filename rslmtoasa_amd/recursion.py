@@ -129,9 +129,10 @@ class Recursion:
 
 
     def timing(self):
-        out = (C.c_double * 10)()
-        self._L.rsrec_get_timing(self._h, out, 10)
-        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a", "hop_mfma_flop", "hop_required_flop")
+        out = (C.c_double * 11)()
+        self._L.rsrec_get_timing(self._h, out, 11)
+        keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a", "hop_mfma_flop", "hop_required_flop",
+                "operator_arrays_from_device")
         return dict(zip(keys, list(out)))
 
     # -- state (restore_to_default, recursion.f90:3713-3825) --------------------------------------------
@@ -169,6 +170,36 @@ class Recursion:
         self._check(self._L.rsrec_set_hamiltonian(self._h, keep["ee"].shape[2], int(bool(ham.hoh)), int(self.control.nsp),
                                                   _ptr(keep["ee"]), _ptr(keep["lsham"]), _ptr(keep["eeo"]), _ptr(keep["enim"]),
                                                   _ptr(keep["hall"]), _ptr(keep["hallo"])))
+
+    def _assemble(self, part, hmag, nbr_type, obarm):
+        hoh = bool(self.hamiltonian.hoh)
+        hm = _fc(hmag, np.complex128)
+        assert hm.ndim == 5 and hm.shape[:2] == (9, 9) and hm.shape[3] == 4, "hmag is (9,9,nslots,4,ncls)"
+        nslots, ncls = hm.shape[2], hm.shape[4]
+        ty = ob = None
+        ntype = 0
+        if hoh:
+            ty, ob = _fc(nbr_type, np.int32), _fc(obarm, np.complex128)
+            assert ty.shape == (nslots, ncls) and ob.shape[:2] == (18, 18)
+            ntype = ob.shape[2]
+        blocks = np.zeros((18, 18, nslots, ncls), np.complex128, order="F")
+        blocks_o = np.zeros_like(blocks) if hoh else None
+        self._check(self._L.rsrec_assemble_blocks(self._h, part, ncls, nslots, int(hoh), _ptr(hm), _ptr(ty), _ptr(ob), ntype, _ptr(blocks), _ptr(blocks_o)))
+        return blocks, blocks_o
+
+    def build_bulkham(self, hmag, nbr_type=None, obarm=None):
+        """hamiltonian%build_bulkham after chbar_nc (hamiltonian.f90:1553-1616), on the device: ee (and eeo = ee.obar with hoh) of every atom
+        type from the (Hx, Hy, Hz, H0) parts ``hmag`` (9,9,nslots,4,ntype); fills ``self.hamiltonian.ee / .eeo``.  A following
+        update_hamiltonian() finds the blocks on the device."""
+        self.hamiltonian.ee, eeo = self._assemble(0, hmag, nbr_type, obarm)
+        if eeo is not None:
+            self.hamiltonian.eeo = eeo
+
+    def build_locham(self, hmag, nbr_type=None, obarm=None):
+        """hamiltonian%build_locham (hamiltonian.f90:1618-1667): hall / hallo of the first nmax atoms, as build_bulkham."""
+        self.hamiltonian.hall, hallo = self._assemble(1, hmag, nbr_type, obarm)
+        if hallo is not None:
+            self.hamiltonian.hallo = hallo
 
     def _my_sites(self):
         start, end = site_partition(self.rank, self.nprocs, self.lattice.nrec)   # recursion.f90:1816

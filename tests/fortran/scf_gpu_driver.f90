@@ -12,6 +12,7 @@
 !
 ! Environment (tests/test_fortran_dropin.py):
 !   RSREC_HOST_LDOS=1   bands_gpu%device_ldos = F: calculate_fermi sums a downloaded g0 on the host (the inherited routine)
+!   RSREC_HOST_HAM=1    hamiltonian_gpu%device_assembly = F: build_bulkham / build_locham are the reference's host routines
 !   RSREC_DEFER_G0=1    green_gpu%defer_g0 = T: g0 is produced only when a routine reads it
 !   RSREC_RANK, RSREC_NRANKS, RSREC_COMM_FILE   a run of several processes WITHOUT MPI: this process is rank RSREC_RANK of RSREC_NRANKS
 !                       (mpi_mod's rank / numprocs, so get_mpi_variables deals the sites), one GPU each, and the densities of states
@@ -29,6 +30,7 @@ program scf_gpu_driver
    use energy_mod
    use hamiltonian_mod
    use recursion_gpu_mod
+   use hamiltonian_gpu_mod
    use density_of_states_mod
    use green_mod
    use green_gpu_mod
@@ -48,7 +50,7 @@ program scf_gpu_driver
    type(energy), target :: energy_obj
    type(self), target :: self_obj
    type(charge), target :: charge_obj
-   type(hamiltonian), target :: hamiltonian_obj
+   type(hamiltonian_gpu), target :: hamiltonian_obj   ! <-- fourth drop-in: ee / eeo / hall / hallo assembled on the GPU (build_bulkham, build_locham)
    type(recursion_gpu), target :: recursion_obj
    type(green_gpu), target :: green_obj      ! <-- second drop-in: the Green function of the block recursion on the GPU
    type(dos), target :: dos_obj
@@ -59,6 +61,7 @@ program scf_gpu_driver
    character(len=512) :: comm_file
    integer :: ia, elen, estat, crc
    logical :: ldos_only
+   real(c_double) :: tinfo(11)
 
    rank = 0
    numprocs = 1
@@ -109,7 +112,9 @@ program scf_gpu_driver
 
    mix_obj = mix(lattice_obj%lattice, charge_obj)
    energy_obj = energy(lattice_obj%lattice)
-   hamiltonian_obj = hamiltonian(charge_obj)
+   hamiltonian_obj%hamiltonian = hamiltonian(charge_obj)
+   call get_environment_variable('RSREC_HOST_HAM', envv, elen, estat)
+   if (estat == 0 .and. elen > 0) hamiltonian_obj%device_assembly = .false.
    recursion_obj = recursion_gpu(hamiltonian_obj, energy_obj)     ! <-- the one-line change
    dos_obj = dos(recursion_obj, energy_obj)
    green_obj = green_gpu(dos_obj)
@@ -155,13 +160,17 @@ program scf_gpu_driver
       call bands_obj%calculate_fermi()
       call g_timer%stop('ldos-only')
       write (*, '(a,i0,a,l1)') 'ldos-only: device_ldos_calls=', bands_obj%n_device_ldos, ' g0_pending=', green_obj%g0_stale
+      write (*, '(a,i0)') 'device_assemblies=', hamiltonian_obj%n_device_assemblies
    else
       call g_timer%start('self-consistency')
       call self_obj%run()
       call g_timer%stop('self-consistency')
+      write (*, '(a,i0)') 'device_assemblies=', hamiltonian_obj%n_device_assemblies
       call save_state(lattice_obj%symbolic_atoms)
    end if
    call g_timer%stop('Calculation')
    call g_timer%print_report()
+   crc = rsrec_get_timing(rsrec_gpu_context(), tinfo, 11_c_int)
+   write (*, '(a,i0)') 'operator_arrays_from_device=', nint(tinfo(11))
    call rsrec_gpu_shutdown()
 end program scf_gpu_driver

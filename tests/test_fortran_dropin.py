@@ -67,6 +67,12 @@ def test_scf_workflow_with_gpu_recursion(name, tmp_path):
         # ... and the densities of states of calculate_fermi (totaldos.out below) came from the device LDOS stage
         # (fortran/bands_gpu.f90) except in local-axis runs, whose resident coefficients are the un-rotated ones
         assert ("ldos-gpu" in log) == ("local_axis" not in str(case["patch"])), log[-3000:]
+    if "exe" not in case:
+        # ee / eeo / hall / hallo were assembled on the device (fortran/hamiltonian_gpu.f90) and the recursion took them from there
+        n_asm = int(re.search(r"device_assemblies=(\d+)", log).group(1))
+        n_dev = int(re.search(r"operator_arrays_from_device=(\d+)", log).group(1))
+        hoh, imp = ".true." in str(case["patch"].get("hamiltonian", {}).get("hoh", "")), "impurity" in case["inputs"]
+        assert n_asm >= 1 and n_dev == (2 if hoh else 1) * (2 if imp else 1), (n_asm, n_dev, log[-1500:])
     if "'chebyshev'" in str(case["patch"]) and "exe" not in case:
         assert "chebyshev-green-gpu" in log, log[-3000:]
     at, rt = case["abs_tol"], case["rel_tol"]
@@ -108,7 +114,7 @@ def test_density_of_states_without_g0(name, tmp_path):
     outs = {}
     # (the device run also brings up the library's own communicator through a file -- one rank: the box has one GPU)
     for mode, env in (("device", {"RSREC_LDOS_ONLY": "1", "RSREC_DEFER_G0": "1", "RSREC_RANK": "0", "RSREC_NRANKS": "1", "RSREC_COMM_FILE": str(tmp_path / "comm.id")}),
-                      ("host", {"RSREC_LDOS_ONLY": "1", "RSREC_HOST_LDOS": "1"})):
+                      ("host", {"RSREC_LDOS_ONLY": "1", "RSREC_HOST_LDOS": "1", "RSREC_HOST_HAM": "1"})):
         work = tmp_path / mode
         shutil.copytree(os.path.join(SCF, case["inputs"]), work)
         inp = work / "input.nml"
@@ -119,9 +125,11 @@ def test_density_of_states_without_g0(name, tmp_path):
         if mode == "device":
             assert "ldos-only: device_ldos_calls=1 g0_pending=T" in log and "library communicator: rank 0 of 1" in log, log[-2000:]
             assert "ldos-gpu" in log and "bgreen-gpu" not in log, log[-3000:]            # no Green-function download in this flow
+            assert "device_assemblies=0" not in log and "operator_arrays_from_device=0" not in log, log[-2000:]
         else:
             assert "ldos-only: device_ldos_calls=0 g0_pending=F" in log, log[-2000:]
             assert "bgreen-gpu" in log and "ldos-gpu" not in log, log[-3000:]
+            assert "device_assemblies=0" in log and "operator_arrays_from_device=0" in log, log[-2000:]      # the reference's host build_bulkham / build_locham
         outs[mode] = {fn: [[fortran_float(v) for v in line.split()] for line in (work / fn).read_text().splitlines()]
                       for fn in sorted(os.listdir(work)) if fn == "totaldos.out" or fn.endswith("_dos.out")}
     assert set(outs["device"]) == set(outs["host"]) and len(outs["device"]) >= 3
