@@ -182,11 +182,21 @@ def build_workload(args, world):
         irec = np.concatenate([np.arange(1, nmax + 1), host])[:nsites_total].astype(np.int32)
         what = "B2 FeCo impurity cluster of the reference's impurity/B2FeCo case: %d atoms, %d of them with per-atom hall blocks, 3 bulk types" % (kk, nmax)
     W.update(nn=g["nn"], iz=g["iz"], nmax=int(g.get("nmax", 0)), ntype=g["ee"].shape[3], ee=g["ee"], lsham=g["lsham"], eeo=g.get("eeo") if args.hoh else None,
-             enim=g.get("enim") if args.hoh else None, hall=g.get("hall"), hallo=g.get("hallo") if args.hoh else None, cr=None, irec=irec,
+             enim=g.get("enim") if args.hoh else None, hall=g.get("hall"), hallo=g.get("hallo") if args.hoh else None,
+             cr=None if args.no_positions else cluster_positions(args.workload, g), irec=irec,
              name="%s; nsp=2 18x18 blocks, %s%s LL=%d, %d sites per GPU per step" % (what, "hoh " if args.hoh else "", "block Lanczos" if args.recur == "block" else "Chebyshev", args.lld, args.sites),
              key="%s%s_%s_s%d_l%d" % (args.recur, "_hoh" if args.hoh else "", args.workload, args.sites, args.lld),
              data="lattice tables and Hamiltonian blocks of the reference's own %s case (committed fixture tests/golden/, dumped from the compiled reference)" % args.workload)
     return W
+
+
+def cluster_positions(workload, g):
+    """lattice%cr of the reference run behind the fixture (tests/golden/<workload>_cr.npz): the locality hint the Fortran drop-in passes too."""
+    import numpy as np
+    with np.load(os.path.join(ROOT, "tests", "golden", workload + "_cr.npz"), allow_pickle=False) as z:
+        cr = z["cr"]
+    assert cr.shape == (3, int(g["kk"]))
+    return cr
 
 
 FCC_PRIMITIVE = [[0.0, 0.5, 0.5], [0.5, 0.0, 0.5], [0.5, 0.5, 0.0]]      # lattice.f90 bravais, fcc, units of alat

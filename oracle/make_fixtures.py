@@ -442,6 +442,37 @@ def run_hmag_case(name):
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+POSITION_CASES = {"fccCu001_cr": "fccCu001_cheb", "B2FeCo_cr": "B2FeCo_block_hoh"}
+
+
+def run_position_case(name):
+    """<name>.npz: lattice%cr(3,kk) of the reference run behind the fixture POSITION_CASES[name] (the other fixtures drop it: the recursion's
+    arithmetic never reads positions).  The Fortran drop-in hands cr to rsrec_set_positions as a locality hint; bench.py does the same for
+    the two multi-class workloads with this file."""
+    base_name = POSITION_CASES[name]
+    case_dir, patch = CASES[base_name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_cr_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        q = os.path.join(scratch, "input.nml")
+        txt = patch_namelist(open(q).read(), patch)
+        open(q, "w").write(txt)
+        r = run_ref(os.path.join(HERE, "_ref", "dump_fixture.x"), scratch)
+        if r.returncode != 0 or not os.path.exists(os.path.join(scratch, "fixture.bin")):
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_fixture failed for " + name)
+        d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
+        base = fio.load_golden(os.path.join(GOLD, base_name + ".npz"))
+        assert np.array_equal(base["nn"], d["nn"]) and np.array_equal(base["iz"], d["iz"]), "lattice of this run differs from %s.npz" % base_name
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), cr=d["cr"], lattice_of=np.array(base_name))
+        print("%-24s kk=%d -> %.1f KB" % (name, d["kk"], os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1024))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def spread_case(name, threads=(1, 2, 8)):
     """<name>_spread.npz: the compiled reference's OWN run-to-run spread on a supercell case -- the same ref_kernel.x run at
     several OpenMP thread counts (its reductions are `omp reduction` sums, recursion.f90:1638-1645: the summation order depends
@@ -464,13 +495,15 @@ def spread_case(name, threads=(1, 2, 8)):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES) + [c + "_hmag" for c in HMAG_CASES]
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES) + [c + "_hmag" for c in HMAG_CASES] + list(POSITION_CASES)
                             + ["sc_4x4x8_block_spread", "sc_4x4x8_block_hoh_spread"])
     for n in want:
         if n in KUBO_CASES:
             run_kubo_case(n)
         elif n in ORBITAL_CASES:
             run_orbital_case(n)
+        elif n in POSITION_CASES:
+            run_position_case(n)
         elif n.endswith("_hmag"):
             run_hmag_case(n[:-len("_hmag")])
         elif n.endswith("_spread"):
