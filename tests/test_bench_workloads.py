@@ -36,7 +36,7 @@ def test_workloads_and_reference_flop_count():
     # one chain of the 22^3 cell, LL = 50: 6 144 075 block multiplies, 420 252 post-hop atom-steps
     assert b.algorithmic_work(W["nn"], 1, 49, False) == (6144075.0, 420252.0)
     Wf = b.build_workload(Args(workload="fccCu001", recur="chebyshev"), 1)
-    assert Wf["key"] == "chebyshev_fccCu001_s64_l50" and Wf["nn"].shape == (9318, 20) and Wf["ntype"] == 3 and Wf["cr"] is None
+    assert Wf["key"] == "chebyshev_fccCu001_s64_l50" and Wf["nn"].shape == (9318, 20) and Wf["ntype"] == 3 and Wf["cr"].shape == (3, 9318)
     Wi = b.build_workload(Args(workload="B2FeCo", hoh=True), 2)
     assert Wi["key"] == "block_hoh_B2FeCo_s64_l50" and Wi["nmax"] == 15 and len(Wi["irec"]) == 128
     assert list(Wi["irec"][:15]) == list(range(1, 16)) and len(set(Wi["irec"].tolist())) == 128 and Wi["irec"].max() <= 4152      # the impurity region first, no site twice
