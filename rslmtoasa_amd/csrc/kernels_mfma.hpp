@@ -128,6 +128,35 @@ __device__ __forceinline__ void gram_block_out(const GramAcc& A, double* lds /*[
     }
 }
 
+// Streamed once per kernel (the post-hop passes read and write whole vectors of several GB: nothing is reused from a cache):
+// RSREC_NT_STREAMS = 1 marks those accesses non-temporal.
+#ifndef RSREC_NT_STREAMS
+#define RSREC_NT_STREAMS 0
+#endif
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) {
+#if RSREC_NT_STREAMS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+#if RSREC_NT_STREAMS
+    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+    const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p));
+    return make_double2(v[0], v[1]);
+#else
+    return *p;
+#endif
+}
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if RSREC_NT_STREAMS
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 #ifndef ADOT_UNROLL
 #define ADOT_UNROLL 4
 #endif
@@ -152,8 +181,8 @@ __global__ __launch_bounds__(MF_WAVES * 64, 2) void k_mfma_adot(ChainView CV, in
 #pragma unroll ADOT_UNROLL
         for (int kq = 0; kq < 36; ++kq) {
             const RowRef rk = group_row(grp, 4 * kq + l4, zero_block);               // k-row of this lane
-            const double p0 = ps[rk.off + l15], p1 = ps[rk.off + 16 + l15], pr = ps[rk.off + 32 + l3];
-            const double h0 = tv[rk.off + l15], h1 = tv[rk.off + 16 + l15], hr = tv[rk.off + 32 + l3];
+            const double p0 = ld_stream(ps + rk.off + l15), p1 = ld_stream(ps + rk.off + 16 + l15), pr = ld_stream(ps + rk.off + 32 + l3);
+            const double h0 = ld_stream(tv + rk.off + l15), h1 = ld_stream(tv + rk.off + 16 + l15), hr = ld_stream(tv + rk.off + 32 + l3);
             A.t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h0, A.t00, 0, 0, 0);
             A.t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, h1, A.t01, 0, 0, 0);
             A.t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, h0, A.t10, 0, 0, 0);

@@ -58,10 +58,10 @@ struct U3Operands { double2 x[4]; double2 y; };           // y: columns 32 + 2 (
 __device__ __forceinline__ void u3_load(U3Operands& o, const double* __restrict__ base, unsigned off, int l4) {
     const double2* p = reinterpret_cast<const double2*>(base + off + 2 * l4);
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) o.x[qq] = p[4 * qq];        // columns 8 qq + 2 l4, +1
+    for (int qq = 0; qq < 4; ++qq) o.x[qq] = ld_stream(p + 4 * qq);        // columns 8 qq + 2 l4, +1
     // the ninth k-step's column 32 + l4 as one more 16-byte load (all five loads of an operand set have the same shape: an 8-byte
     // load here made the register allocator recycle its destination pair as an address temporary -> a vmcnt(0) in the tile loop)
-    o.y = *reinterpret_cast<const double2*>(base + off + 32 + 2 * (l4 >> 1));
+    o.y = ld_stream(reinterpret_cast<const double2*>(base + off + 32 + 2 * (l4 >> 1)));
 }
 
 template <int Q>
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const RowRef rs = tile_row(P.ta, 16 * P.mt + l4 + 4 * j);
-            if (rs.valid) { up[rs.off + l15] = P.ca[j]; up[rs.off + 16 + l15] = P.cb[j]; }
+            if (rs.valid) { st_stream(up + rs.off + l15, (double)P.ca[j]); st_stream(up + rs.off + 16 + l15, (double)P.cb[j]); }
         }
         const RowRef rr = tile_row(P.ta, 16 * P.mt + 4 * lg + l4);
-        if (rr.valid) up[rr.off + 32 + l3] = P.cr;
+        if (rr.valid) st_stream(up + rr.off + 32 + l3, P.cr);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double f0 = P.ca[j], f1 = P.cb[j];
