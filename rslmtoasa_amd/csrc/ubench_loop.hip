@@ -49,6 +49,17 @@ __global__ __launch_bounds__(512, 2) void k_loop(const double* __restrict__ vec,
                         c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b[h][t][e], c[t], 0, 0, 0);
                         r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[e], b[h][t][e], r[t], 0, 0, 0);
                     }
+            } else if (MODE == 2) {
+                // rows 16, 17 of the real form on the vector ALU instead of a 4x4x4 tile: per k-step two v_fma_f64 per tile (partial sums per k lane)
+                const d2 a0 = A[0], a1 = A[64], a2 = A[128];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b[h][t][e], c[t], 0, 0, 0);
+                        r[2 * t] = __builtin_fma(a1[e], b[h][t][e], r[2 * t]);
+                        r[2 * t + 1] = __builtin_fma(a2[e], b[h][t][e], r[2 * t + 1]);
+                    }
             } else {
                 const d2 a0 = A[0], a1 = A[64];
                 const double ar[3] = {a0[0], a0[1], a1[0]};
@@ -86,7 +97,7 @@ void run(const char* name, const double* vec, size_t nblocks, int blocks, int st
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double cyc = ms * 1e-3 * 2.4e9 / steps / 2.0;            // two waves share a SIMD: SIMD cycles per step per wave
-    printf("%-46s %8.3f ms for %d steps: %7.1f SIMD cycles per step and wave (matrix cycles nominal: %d)\n", name, ms, steps, cyc, MODE == 0 ? 1440 : 864);
+    printf("%-46s %8.3f ms for %d steps: %7.1f SIMD cycles per step and wave (matrix cycles nominal: %d)\n", name, ms, steps, cyc, MODE == 0 ? 1440 : MODE == 1 ? 864 : 1152);
     CK(hipFree(out));
 }
 
@@ -101,7 +112,9 @@ int main(int argc, char** argv) {
     const int blocks = p.multiProcessorCount;          // one 8-wave workgroup per CU: two waves per SIMD
     run<0, 1>("A: today's mix (2 k-steps x 9 x (16x16x4 + 4x4x4))", vec, nblocks, blocks, 4000);
     run<1, 1>("B: real-basis mix (18 tiles x 3 row blocks of 4x4x4)", vec, nblocks, blocks, 4000);
+    run<2, 1>("C: 16x16x4 rows + rows 16, 17 on the vector ALU", vec, nblocks, blocks, 4000);
     run<0, 0>("A without the gathers", vec, nblocks, blocks, 4000);
+    run<2, 0>("C without the gathers", vec, nblocks, blocks, 4000);
     run<1, 0>("B without the gathers", vec, nblocks, blocks, 4000);
     return 0;
 }
