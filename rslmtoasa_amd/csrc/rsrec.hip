@@ -399,9 +399,6 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
     else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
     else if (!strcmp(key, "cheb_fused")) h->opt_cheb_fused = value;
-    else if (!strcmp(key, "s5_lds")) h->opt_s5_lds = value;
-    else if (!strcmp(key, "s5_queue")) h->opt_s5_queue = value;
-    else if (!strcmp(key, "cheb_fused")) h->opt_cheb_fused = value;
     else if (!strcmp(key, "side_stream")) h->opt_side = value;
     else if (!strcmp(key, "graph")) h->opt_graph = value;
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
