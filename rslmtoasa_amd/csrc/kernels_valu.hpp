@@ -500,6 +500,14 @@ __global__ __launch_bounds__(NTHREADS) void k_scalar_hop(DevProblem P, ChainView
             const double2* x = psi + vo + (size_t)NB * n + off;
 #pragma unroll
             for (int m = 0; m < 9; ++m) cfma(d, H[r + NB * (m + off)], x[m]);
+            if (slot == 0 && !P.hoh) {
+                // the scalar hop reads ee(:,:,1,ih) / hall(:,:,1,i) alone (:3336, :3372), without the spin-orbit block that the block
+                // recursion's on-site term carries (locham = ee + lsham, :1608) and that the on-site table holds folded in: take it out
+                // again (a no-op in the reference's own nsp = 1 runs, where lsham is never built and stays zero)
+                const double2* S = P.lsham + (size_t)BLK * P.iz[i];
+#pragma unroll
+                for (int m = 0; m < 9; ++m) { const double2 sv = S[r + NB * (m + off)]; cfma(d, make_double2(-sv.x, -sv.y), x[m]); }
+            }
         }
         const double2 p = psi[vo + (size_t)NB * i + r];
         asum += d.x * p.x + d.y * p.y;

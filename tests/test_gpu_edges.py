@@ -72,3 +72,23 @@ def test_unchanged_lattice_keeps_the_cached_regions():
     rec.recur_b()
     assert np.abs(rec.a_b[:, :, :, 0] - a0[:, :, :, 0]).max() > 1e-6      # (first visible in A_3: psi_2 vanishes on the seed atom)
     rec.close()
+
+
+@pytest.mark.parametrize("nmax", [0, 3])
+def test_scalar_recursion_ignores_the_spin_orbit_block(nmax, oracle_lib):
+    """The scalar hop reads ee(:,:,1,ih) / hall(:,:,1,i) alone (recursion.f90:3336, :3372): a non-zero `lsham` (never built in the
+    reference's own nsp = 1 runs, so none of its fixtures has one) must not enter, although the block recursion's on-site table carries
+    it.  Found by tools/fuzz_recursion.py; random ragged lattice, several atom types, with and without impurity atoms."""
+    from helpers import rel_err_rows
+    from test_gpu_spmm_random import random_problem
+    rng = np.random.default_rng(4242 + nmax)
+    p = random_problem(rng, 150, 9, 2, nmax, False, True)
+    p["nsp"] = 1
+    assert np.abs(p["lsham"]).max() > 0.0
+    irec = np.array([1, 75, 150], np.int32)
+    lld = 6
+    rec = Recursion(*objects_from(p, irec, lld, nsp=1, llsp=lld), device=0)
+    rec.recur()
+    a_o, b_o = oracle_lib.Oracle(p).scalar_lanczos(irec, lld, lld)
+    assert rel_err_rows(rec.a[:, :, :3, 0], a_o) < RTOL and rel_err_rows(rec.b2[:, :, :3, 0], b_o) < RTOL
+    rec.close()

@@ -48,6 +48,36 @@ if __name__ == "__main__":
             mu_o, div = o.chebyshev(irec, lld, *chebyshev_scaling(-60.0, 60.0))
             errs.append(rel_err(rec.mu_n, mu_o))
             rec.close()
+            extra = ""
+            if nslots >= 5 and rng.random() < 0.3:                # (one or two slots: the pair chains break down after a level or two, nothing to compare)
+                # recur_b_ij / chebyshev_recur_ij: four seeded chains per random atom pair (one pair may be i == j)
+                npair = int(rng.integers(1, 4))
+                pairs = rng.integers(1, kk + 1, (npair, 2)).astype(np.int32)
+                if rng.random() < 0.3:
+                    pairs[0, 1] = pairs[0, 0]
+                ham, lat, ctl, en = objects_from(p, [1], lld, emin=-60.0, emax=60.0)
+                lat.ijpair = pairs
+                rp = Recursion(ham, lat, ctl, en, device=0)
+                for k, v in opts.items():
+                    rp.set_option(k, v)
+                rp.update_hamiltonian()
+                slots, sa, sc = rp._pair_seeds(pairs, skip_diagonal_repeats=True)
+                rp.recur_b_ij()
+                a_p, b_p = o.block_lanczos_seeded(sa, sc, lld)
+                errs += [rel_err(rp.a_b[:, :, :, slots], a_p), rel_err(rp.b2_b[:, :, :, slots], b_p)]
+                rp.close()
+                extra = " +pairs"
+            if collinear and not hoh and rng.random() < 0.3:
+                # scalar Haydock recursion (nsp = 1): 18 orbital chains per site on the spin-diagonal 9x9 blocks
+                from helpers import rel_err_rows
+                p1 = dict(p, nsp=1)
+                rs = Recursion(*objects_from(p1, irec, lld, nsp=1, llsp=lld), device=0)
+                rs.recur()
+                a_s, b_s = oracle.Oracle(p1).scalar_lanczos(irec, lld, lld)
+                errs += [rel_err_rows(rs.a[:, :, :nsites, 0], a_s), rel_err_rows(rs.b2[:, :, :nsites, 0], b_s)]
+                rs.close()
+                extra += " +scalar"
+            tag += extra
             ok = div == 0 and max(errs) < RTOL
             verdict = "ok  " if ok else "FAIL"
             if not ok and div == 0:
