@@ -23,6 +23,19 @@ __global__ __launch_bounds__(256) void k_stream(const d2* __restrict__ a, const 
         for (int u = 0; u < U; ++u) x[u] = ld<NT>(a + base + u * 256 + threadIdx.x);
 #pragma unroll
         for (int u = 0; u < U; ++u) y[u] = ld<NT>(b + base + u * 256 + threadIdx.x);
+        if (MODE == 2) {
+            // the same two read streams with 8-byte loads (two per 16 bytes), as k_mfma_adot / k_mfma_cheb issue them
+            const double* a8 = reinterpret_cast<const double*>(a + base);
+            const double* b8 = reinterpret_cast<const double*>(b + base);
+            double xs[2 * U], ys[2 * U];
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) xs[u] = a8[u * 256 + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) ys[u] = b8[u * 256 + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) acc[0] += xs[u] * ys[u];
+            continue;
+        }
         if (MODE == 1) {
 #pragma unroll
             for (int u = 0; u < U; ++u) z[u] = ld<NT>(c + base + u * 256 + threadIdx.x);
@@ -33,7 +46,7 @@ __global__ __launch_bounds__(256) void k_stream(const d2* __restrict__ a, const 
             for (int u = 0; u < U; ++u) acc += x[u] * y[u];
         }
     }
-    if (MODE == 0 && acc[0] + acc[1] == 12345.678) sink[0] = acc[0];
+    if (MODE != 1 && acc[0] + acc[1] == 12345.678) sink[0] = acc[0];
 }
 
 template <int MODE, int U, int NT>
@@ -53,8 +66,8 @@ void run(size_t n, int cus, int wg_per_cu, d2* a, d2* b, d2* c, double* sink) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    const double streams = MODE == 0 ? 2.0 : 4.0;
-    printf("%-5s U=%d %s wg/CU=%-2d footprint/stream %.2f GB: %7.3f ms  %5.2f TB/s\n", MODE == 0 ? "2R" : "3R1W", U, NT ? "nt " : "def", wg_per_cu, n * 16e-9, best,
+    const double streams = MODE == 1 ? 4.0 : 2.0;
+    printf("%-5s U=%d %s wg/CU=%-2d footprint/stream %.2f GB: %7.3f ms  %5.2f TB/s\n", MODE == 0 ? "2R" : MODE == 1 ? "3R1W" : "2R-8B", U, NT ? "nt " : "def", wg_per_cu, n * 16e-9, best,
            streams * n * 16 / best * 1e-9);
 }
 
@@ -78,6 +91,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(a, 0, nmax * 16)); CK(hipMemset(b, 0, nmax * 16)); CK(hipMemset(c, 0, nmax * 16));
     for (size_t n : {nmax, nmax / 8}) {
         sweep<0, 0>(n, cus, a, b, c, sink);
+        sweep<2, 0>(n, cus, a, b, c, sink);
         sweep<0, 1>(n, cus, a, b, c, sink);
         sweep<1, 0>(n, cus, a, b, c, sink);
         sweep<1, 1>(n, cus, a, b, c, sink);
