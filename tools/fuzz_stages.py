@@ -59,6 +59,10 @@ if __name__ == "__main__":
             g0 = gr.block_green(a_inf, b_inf, eta=eta, nsites=nsites).copy()
             g0o = np.stack([oracle.block_green(rec.a_b[:, :, :, s], rec.b2_b[:, :, :, s], ene, a_inf[:, :, s], b_inf[:, :, s], eta=eta, sym_term=sym) for s in range(nsites)], axis=3)
             errs["green"] = rel(g0, g0o)
+            # conditioning of the continued fraction on this mesh: the oracle's own answer for energies shifted by 1e-14 (a mesh point next to a
+            # pole of a short chain on the real axis amplifies rounding by 1e6 and more, in either code)
+            g0s = np.stack([oracle.block_green(rec.a_b[:, :, :, s], rec.b2_b[:, :, :, s], ene * (1 + 1e-14) + 1e-15, a_inf[:, :, s], b_inf[:, :, s], eta=eta, sym_term=sym) for s in range(nsites)], axis=3)
+            sens = rel(g0s, g0o)
             dt, da, dl = ldos_from_g0(g0o)
             # the densities are -Im g0_jj / pi: outside the band (or with a real eta) that imaginary part is rounding noise of |g0|, and near a
             # pole of a short chain the inverse is ill-conditioned in both codes -- the scale of the comparison is |g0|, not the density
@@ -69,7 +73,9 @@ if __name__ == "__main__":
             gco = np.stack([oracle.chebyshev_green(rec.mu_n[:, :, :, s], ene, -6.0, 6.0) for s in range(nsites)], axis=3)
             errs["cheb_green"] = rel(gc, gco)
             rec.close()
-            tol = {"zsqr": 1e-12, "term": 1e-12, "green": 1e-10, "ldos": 1e-10, "cheb_green": 1e-11}
+            tol = {"zsqr": 1e-12, "term": 1e-12, "green": max(1e-10, 10 * sens), "ldos": max(1e-10, 10 * sens), "cheb_green": 1e-11}
+            if sens > 1e-11:
+                tag += " (ill-conditioned mesh point: oracle sensitivity %.1e)" % sens
             ok = all(errs[k] <= tol[k] for k in tol)
             print("%s %s  %s" % ("ok  " if ok else "FAIL", tag, " ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
             bad += 0 if ok else 1
