@@ -257,6 +257,8 @@ int rsrec_comm_destroy(rsrec_t *h);
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
  *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none],
  *   "s5_lds"     k_spmm5 with the operator fragments in LDS for operators with one class of atoms: 0 = never, 1 = whenever it applies [1]
+ *   "s5_octet"   atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS of the batch (they then share
+ *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [64]
  *   "s5_queue"   that form as 256 persistent workgroups with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
  *                workgroups, 2 = always [1] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
@@ -271,6 +273,7 @@ int rsrec_set_option(rsrec_t *h, const char *key, long value);
  *          18x18 blocks (46 656 flop each, recursion.f90:1618); a spin-diagonal block (every hopping block of a collinear magnet,
  *          hamiltonian.f90:1553-1617) needs 23 328, a spin-mixing block 46 656 -- the unit roofline fractions are quoted in.
  *   out[10] block arrays (0..4: ee, eeo, hall, hallo) the last rsrec_set_hamiltonian took from rsrec_assemble_blocks' device copies.
+ *   out[11] H|psi> launches of the last call in which the atoms with their own operator blocks were grouped over 8 chains (option "s5_octet").
  * After rsrec_block_green: out[0] = kernel + transfers, out[1] = the Green kernel alone. */
 int rsrec_get_timing(rsrec_t *h, double *out, int n);
 

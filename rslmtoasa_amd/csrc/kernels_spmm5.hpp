@@ -423,13 +423,16 @@ typedef const S5_GLOBAL char* s5_gp;      // explicit global address space: the 
 // TWO: the first two entries (18 orbitals = steps 0..4 of the first period) are the extra on-site slot; they read the second input
 // vector in2b (hoh second pass, recursion.f90:1543: the (e_nu + l.s) term acts on psi itself; local-axis runs: the per-chain on-site
 // term), and if fr_head is given the first two triples of fragments come from that per-chain table.
-template <bool TWO, bool LDSA>
+// OCT: the 8 tiles are 8 CHAINS on one atom (atom[] holds that atom 8 times, or the zero block for a chain that does not exist): tile t reads
+// the neighbour block of chain c0 + t, which lies tile_blk[t] = t (kk + 1) blocks behind chain c0's in the batch's vectors.
+template <bool TWO, bool LDSA, bool OCT = false>
 __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict__ meta, const char* __restrict__ fr /*LDSA: the staged stream in LDS*/, const char* __restrict__ fr_head,
                                               const char* __restrict__ inb, const char* __restrict__ in2b,
                                               const int* __restrict__ nbr5 /*(kk+1) x ncol: absent -> zero block, column nslots = self, nslots + 1 = zero block*/,
                                               const int (&atom)[GROUP] /*padding -> zero block*/, int rem_sel /*per lane: tile (atom of the group) of its remainder column*/,
                                               int ncol, int sig, int l4,
-                                              unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8) {
+                                              unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8,
+                                              const int (&tile_blk)[GROUP], int rem_blk /*per lane: tile_blk of its remainder tile*/) {
     int left = meta[0];
     if (left <= 0) return;
     const bool extras = TWO && meta[1] != 0;
@@ -452,11 +455,11 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
     auto open_entry = [&](int j, S5Ent& E) {
         const unsigned so = 2592u * (unsigned)((code_cur >> 8) ? 1 - sig : sig);
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) E.off[t] = (unsigned)raw[t] * (BLD * 8u) + so;
+        for (int t = 0; t < GROUP; ++t) E.off[t] = (unsigned)(OCT ? raw[t] + tile_blk[t] : raw[t]) * (BLD * 8u) + so;
         // remainder tile: this lane's atom is tile rem_sel = l15 >> 1 of the group -- selected from the scalar indices
         const int r01 = (rem_sel & 1) ? raw[1] : raw[0], r23 = (rem_sel & 1) ? raw[3] : raw[2], r45 = (rem_sel & 1) ? raw[5] : raw[4], r67 = (rem_sel & 1) ? raw[7] : raw[6];
         const int r03 = (rem_sel & 2) ? r23 : r01, r47 = (rem_sel & 2) ? r67 : r45;
-        E.rem = (unsigned)((rem_sel & 4) ? r47 : r03) * (BLD * 8u) + so;
+        E.rem = (unsigned)(((rem_sel & 4) ? r47 : r03) + (OCT ? rem_blk : 0)) * (BLD * 8u) + so;
         code_cur = code_nxt;
         code_nxt = codes[j + 2];
         load_idx(code_cur & 255);
@@ -556,7 +559,11 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
 // level); its Gram matrices are formed by k_mfma_cheb<., true> in one pass over cur and out.
 struct S5Epilogue { int kind = 0; const double* cur = nullptr; const double* old = nullptr; double a = 1.0, b = 0.0; };
 
-template <bool TWO, bool LDSA>
+// OCT (global-load form only): a group is ONE atom with its own operator blocks (class tau < nmax) and its 8 tiles are 8 chains of the
+// batch -- blockIdx.y counts octets of chains, the groups are the run [run_lo, run_hi) of the class-sorted list of all atoms, which
+// every chain of the launch must be on (the host launches this form only then).  Chains share an atom's fragments the way 8 atoms of a
+// type do; as groups of their own such atoms fill one tile of nine.
+template <bool TWO, bool LDSA, bool OCT = false>
 __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+2)*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta, int ntr,
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int ncol = D.nslots + 2;
     // grid.y may be smaller than the number of chains ("chain_fold"): a workgroup then serves chains blockIdx.y, + gridDim.y, ...
 #pragma unroll 1
-    for (int chain = blockIdx.y; chain < D.nchains; chain += gridDim.y) {
+    for (int chain = OCT ? GROUP * (int)blockIdx.y : (int)blockIdx.y; chain < D.nchains; chain += OCT ? GROUP * (int)gridDim.y : (int)gridDim.y) {
     const int count = cum[(chain / D.cpo) * D.nlev + D.level];
     int ngroups = count / GROUP;
     const int ob = D.obase[(chain / D.cpo) * D.nlev + D.level];
@@ -695,12 +702,29 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         }
         const int* __restrict__ grp = order + (size_t)g * GROUP;
         int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the step loop
+        int vatom[GROUP], tile_blk[GROUP];                  // OCT: block index of tile t's own atom seen from chain c0's vectors; its neighbour blocks' shift
+        int my_rem_atom, rem_blk = 0;
+        if constexpr (OCT) {
+            const int a0 = grp[0];                          // the group's one atom (a class run of per-atom blocks: one atom, seven padding entries)
 #pragma unroll
-        for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; atom[t] = a >= 0 ? a : zero_block; }
+            for (int t = 0; t < GROUP; ++t) {
+                const bool ok = a0 >= 0 && chain + t < D.nchains;
+                atom[t] = ok ? a0 : zero_block;
+                tile_blk[t] = ok ? t * (D.kk + 1) : 0;
+                vatom[t] = ok ? a0 + t * (D.kk + 1) : zero_block;
+            }
+            const int tr = l15 >> 1;
+            const bool okr = a0 >= 0 && chain + tr < D.nchains;
+            rem_blk = okr ? tr * (D.kk + 1) : 0;
+            my_rem_atom = okr ? a0 + tr * (D.kk + 1) : zero_block;
+        } else {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; atom[t] = a >= 0 ? a : zero_block; vatom[t] = atom[t]; tile_blk[t] = 0; }
+            my_rem_atom = grp[l15 >> 1];
+            my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
+        }
         const int first = atom[0];
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
-        int my_rem_atom = grp[l15 >> 1];
-        my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
         const char* __restrict__ fr = LDSA ? reinterpret_cast<const char*>(s5_lds) : reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);
         const char* __restrict__ fh = (TWO && frag_head) ? reinterpret_cast<const char*>(frag_head + ((size_t)chain * ntau + tau) * S5_HEAD_DOUBLES + (size_t)sig * S5_HEAD_TRIPLES * S5_TRIPLE) : nullptr;
@@ -709,7 +733,8 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #pragma unroll
         for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
 
-        s5_run_stream<TWO, LDSA>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
+        if constexpr (OCT) s5_run_stream<TWO, LDSA, true>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8, tile_blk, rem_blk);
+        else s5_run_stream<TWO, LDSA>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8, tile_blk, rem_blk);
 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI
@@ -720,7 +745,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NT = T1 - T0;
             size_t eo[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) { const int t = T0 + i; eo[i] = (size_t)BLD * ((t < 8) ? atom[t] : my_rem_atom) + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1)); }
+            for (int i = 0; i < NT; ++i) { const int t = T0 + i; eo[i] = (size_t)BLD * ((t < 8) ? vatom[t] : my_rem_atom) + 324 * sig + ((t < 8) ? 2 * l15 : 32 + 2 * (l15 & 1)); }
             s5_d2 ec[NT][2], ez[NT][2];
             double ecr[NT], ezr[NT];
             if (epi.kind) {
@@ -744,7 +769,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int t = T0 + i;
-                const int a = (t < 8) ? atom[t] : my_rem_atom;
+                const int a = (t < 8) ? vatom[t] : my_rem_atom;
                 double* ob = out + eo[i];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {

@@ -96,6 +96,7 @@ struct rsrec_handle {
     DevBuf d_asm[2][2], d_asm_in;
     std::vector<double> asm_host[2][2];
     int asm_nslots[2] = {0, 0}, asm_ncls[2] = {0, 0}, asm_hoh[2] = {0, 0};
+    int n_octet_launch = 0;      // launches of the last call that formed the groups of per-atom-block atoms over 8 chains (k_spmm5<., false, true>)
     int n_asm_reused = 0;        // block arrays the last rsrec_set_hamiltonian took from those device copies (0..4)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
@@ -112,6 +113,7 @@ struct rsrec_handle {
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
+    long opt_s5_octet = 64;      // atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS instead of one atom + 7 padding tiles (0: never)
     long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
     int n_kubo_left_chunks = 0;
@@ -405,6 +407,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
+    else if (!strcmp(key, "s5_octet")) h->opt_s5_octet = value;
     else if (!strcmp(key, "s5_run_min")) h->opt_s5_run_min = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -412,9 +415,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
 
 extern "C" int rsrec_get_timing(rsrec_t* h, double* out, int n) {
     if (!h || !out) return RSREC_ERR_ARG;
-    const double v[11] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop,
-                          h->n_req_flop, (double)h->n_asm_reused};
-    for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
+    const double v[12] = {h->t_total_ms, h->t_hop_ms, h->n_hop_launch, h->n_atom_steps, h->n_block_mult, h->t_rest_ms, h->t_host_ms, (double)h->hop_fuses_a, h->n_hop_mfma_flop,
+                          h->n_req_flop, (double)h->n_asm_reused, (double)h->n_octet_launch};
+    for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
     return RSREC_OK;
 }
 
@@ -880,6 +883,7 @@ double required_hop_flops(const rsrec_t* h, const Spmm5Operator& op) {
 void reset_timing(rsrec_t* h) {
     h->t_total_ms = h->t_hop_ms = h->t_rest_ms = h->t_host_ms = 0;
     h->n_hop_launch = h->n_atom_steps = h->n_block_mult = h->n_hop_mfma_flop = h->n_req_flop = 0;
+    h->n_octet_launch = 0;
     h->ev_used = 0;
 }
 
@@ -1015,6 +1019,25 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
     // so it is not the default; the parity tests run it)
     const bool multi = one < 0 && h->opt_s5_lds >= 2 && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.level >= 0 && SD.level < (int)E->level_sat.size() &&
                        E->level_sat[SD.level] > 0 && op.ntau == h->nmax + h->ntype && (grid.x >= (unsigned)std::max(16, h->n_cu / 16 * 16) || h->opt_s5_queue >= 2) && (size_t)op.ntr * S5_TRIPLE * sizeof(double) <= (s5_prepare(h), h->s5_lds_limit);
+    // Atoms with their own operator blocks (an impurity region: classes 0 .. nmax - 1, the first nmax groups of the class-sorted list of all
+    // atoms, one atom + seven padding tiles each): once EVERY chain of the batch is on that list their groups are formed over 8 chains
+    // instead -- the chains share the atom's fragments -- by a launch of their own; the main launch skips them.
+    bool octets = false;
+    if (!multi && one < 0 && h->opt_s5_octet > 0 && h->nmax >= h->opt_s5_octet && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.nchains >= 2 && SD.level >= 0 &&
+        SD.level < (int)E->level_sat.size() && E->level_sat[SD.level] == SD.nchains && op.ntau == h->nmax + h->ntype &&
+        (double)GROUP * (double)(h->kk + 1) * BLD * 8.0 < 4294967296.0 && (int)E->sat_runs.size() >= h->nmax &&
+        E->sat_runs[0].tau == 0 && E->sat_runs[0].lo == 0 && E->sat_runs[h->nmax - 1].tau == h->nmax - 1 && E->sat_runs[h->nmax - 1].hi == h->nmax) {
+        // (the list is sorted by class, per-atom classes first: groups 0 .. nmax - 1 are those atoms, one each)
+        SpmmDims SO = SD;
+        SO.sat_base = E->sat_base; SO.run_lo = 0; SO.run_hi = h->nmax;
+        const dim3 go((unsigned)((h->nmax + S5_WG_GROUPS - 1) / S5_WG_GROUPS), (unsigned)((SD.nchains + GROUP - 1) / GROUP));
+        k_spmm5<TWO, false, true><<<go, S5_WG_GROUPS * 128, 0, h->stream>>>(SO, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau,
+                                                                          0, nullptr, 1, epi);
+        // the main launch takes the rest of that list as ONE run (every chain is on it), so that its XCD chunks are cut from what it serves
+        SD.sat_base = E->sat_base; SD.run_lo = h->nmax; SD.run_hi = E->sat_runs.back().hi;
+        octets = true;
+        h->n_octet_launch++;
+    }
     if (!multi) launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, extra, ntau, epi, one);
     else {
         // class runs worth workgroups of their own: at least two groups per workgroup of a full persistent launch over the chains on the list
@@ -1054,7 +1077,11 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
         launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, nullptr, ntau, epi, -1);
     }
     if (h->cur_level_groups && SD.level >= 0 && (size_t)(SD.level + 1) * op.ntau <= h->cur_level_groups->size() && SD.cpo == 1 && op.ntau == h->nmax + h->ntype)
-        for (int t = 0; t < op.ntau; ++t) h->n_hop_mfma_flop += (*h->cur_level_groups)[(size_t)SD.level * op.ntau + t] * op.flops_per_group(set, t);
+        for (int t = 0; t < op.ntau; ++t) {
+            double groups = (*h->cur_level_groups)[(size_t)SD.level * op.ntau + t];
+            if (octets && t < h->nmax) groups = (double)((SD.nchains + GROUP - 1) / GROUP);          // one group per octet of chains instead of one per chain
+            h->n_hop_mfma_flop += groups * op.flops_per_group(set, t);
+        }
 }
 
 // k_spmm4 addresses a chain's vector with 32-bit byte offsets: only below 4 GiB per chain vector (828 000 atoms)
@@ -1312,7 +1339,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
                                           (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
                                           (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
-                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing};
+                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet};
             for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
             if (!h->graph_exec || key != h->graph_key) {
                 if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }

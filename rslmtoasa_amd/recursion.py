@@ -129,10 +129,10 @@ class Recursion:
 
 
     def timing(self):
-        out = (C.c_double * 11)()
-        self._L.rsrec_get_timing(self._h, out, 11)
+        out = (C.c_double * 12)()
+        self._L.rsrec_get_timing(self._h, out, 12)
         keys = ("total_ms", "hop_ms", "hop_launches", "atom_steps", "block_multiplies", "rest_ms", "host_ms", "hop_fuses_a", "hop_mfma_flop", "hop_required_flop",
-                "operator_arrays_from_device")
+                "operator_arrays_from_device", "octet_launches")
         return dict(zip(keys, list(out)))
 
     # -- state (restore_to_default, recursion.f90:3713-3825) --------------------------------------------

@@ -92,3 +92,38 @@ def test_scalar_recursion_ignores_the_spin_orbit_block(nmax, oracle_lib):
     a_o, b_o = oracle_lib.Oracle(p).scalar_lanczos(irec, lld, lld)
     assert rel_err_rows(rec.a[:, :, :3, 0], a_o) < RTOL and rel_err_rows(rec.b2[:, :, :3, 0], b_o) < RTOL
     rec.close()
+
+
+@pytest.mark.parametrize("hoh", [False, True])
+@pytest.mark.parametrize("nsites", [2, 11])
+def test_per_atom_blocks_grouped_over_chains(nsites, hoh, oracle_lib):
+    """Atoms with their own operator blocks (`hall`, an impurity region) are one-tile groups; option s5_octet forms their groups over 8
+    chains of the batch once every chain's region covers the lattice (k_spmm5<., false, true>).  Nine such atoms with DIFFERENT blocks in a
+    128-atom periodic cell, a full and a partial octet of chains, +- hoh: block Lanczos and Chebyshev moments against the oracle, and the
+    same numbers, bit for bit, as without the option (the grouping changes no summation order)."""
+    rng = np.random.default_rng(99)
+    p = dict(supercell_problem((4, 4, 8), hoh=hoh))
+    nmax = 9
+    scale = 1.0 + 0.05 * rng.standard_normal(nmax)
+    p["nmax"] = nmax
+    p["hall"] = np.asfortranarray(p["ee"][:, :, :, :1] * scale)
+    if hoh:
+        p["hallo"] = np.asfortranarray(p["eeo"][:, :, :, :1] * scale)
+    irec = rng.choice(128, nsites, replace=False).astype(np.int32) + 1
+    lld = 9
+    rec = Recursion(*objects_from(p, irec, lld, emin=-3.0, emax=1.8), device=0)
+    rec.set_option("s5_octet", 0)
+    rec.recur_b(); rec.chebyshev_recur()
+    a0, b0, m0 = rec.a_b.copy(), rec.b2_b.copy(), rec.mu_n.copy()
+    assert rec.timing()["octet_launches"] == 0
+    rec.set_option("s5_octet", 1)
+    rec.recur_b()
+    assert rec.timing()["octet_launches"] > 0
+    rec.chebyshev_recur()
+    assert rec.timing()["octet_launches"] > 0
+    assert np.array_equal(rec.a_b, a0) and np.array_equal(rec.b2_b, b0) and np.array_equal(rec.mu_n, m0)
+    o = oracle_lib.Oracle(p)
+    a_o, b_o = o.block_lanczos(irec, lld)
+    mu_o, div = o.chebyshev(irec, lld, *chebyshev_scaling(-3.0, 1.8))
+    assert div == 0 and rel_err(rec.a_b, a_o) < RTOL and rel_err(rec.b2_b, b_o) < RTOL and rel_err(rec.mu_n, mu_o) < RTOL
+    rec.close()

@@ -14,7 +14,7 @@ from oracle import oracle
 from rslmtoasa_amd.recursion import Recursion, chebyshev_scaling
 
 OPTIONS = {"kernels": (0, 1, 2), "spmm5": (0, 1, 2), "s5_lds": (0, 1, 2), "s5_queue": (0, 1, 2), "s5_run_min": (0, 1), "graph": (0, 1, 2), "orth3": (1, 2),
-           "batch": (0, 1, 3), "chain_fold": (1, 2), "s5_host_emit": (0, 1), "side_stream": (0, 1), "cheb_fused": (0, 1), "s5_waves": (4, 8)}
+           "batch": (0, 1, 3), "chain_fold": (1, 2), "s5_host_emit": (0, 1), "s5_octet": (0, 1, 1), "side_stream": (0, 1), "cheb_fused": (0, 1), "s5_waves": (4, 8)}
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -40,15 +40,17 @@ if __name__ == "__main__":
             rec.update_hamiltonian()                              # (options that shape the operator tables apply from the next hand-over)
             o = oracle.Oracle(p)
             errs = []
+            noct = 0
             for rep in range(2):                                  # twice: the second call reuses cached regions / a captured graph
                 rec.recur_b()
+                noct += int(rec.timing()["octet_launches"])
                 a_o, b_o = o.block_lanczos(irec, lld)
                 errs += [rel_err(rec.a_b, a_o), rel_err(rec.b2_b, b_o)]
             rec.chebyshev_recur()
             mu_o, div = o.chebyshev(irec, lld, *chebyshev_scaling(-60.0, 60.0))
             errs.append(rel_err(rec.mu_n, mu_o))
             rec.close()
-            extra = ""
+            extra = " [octet launches %d]" % noct if noct else ""
             if nslots >= 5 and rng.random() < 0.3:                # (one or two slots: the pair chains break down after a level or two, nothing to compare)
                 # recur_b_ij / chebyshev_recur_ij: four seeded chains per random atom pair (one pair may be i == j)
                 npair = int(rng.integers(1, 4))

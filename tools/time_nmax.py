@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Cost of per-atom operator blocks (`hall`, the first nmax atoms; hamiltonian.f90:1618): the same periodic bcc cell with nmax = 0, 15, 200, 1000
-atoms carrying their own (identical) copies of the stencil.  Block Lanczos, 16 sites, LL = 20."""
+"""Cost of per-atom operator blocks (`hall`, the first nmax atoms; hamiltonian.f90:1618): the same periodic bcc cell with nmax = 0 ... 1000
+atoms carrying their own (identical) copies of the stencil, with their groups formed per atom (s5_octet = 0) and over 8 chains (s5_octet = 1).
+Block Lanczos, LL = 20.   tools/time_nmax.py [sites]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +15,9 @@ if __name__ == "__main__":
     for hoh in (False, True):
         base = supercell_problem(dims, hoh=hoh)
         kk = base["nn"].shape[0]
-        irec = spread_sites(kk, 16)
+        irec = spread_sites(kk, int(sys.argv[1]) if len(sys.argv) > 1 else 16)
         ref = None
-        for nmax in (0, 15, 200, 1000):
+        for nmax in (0, 15, 32, 64, 200, 1000):
             p = dict(base, nmax=nmax)
             if nmax:
                 p["hall"] = np.asfortranarray(np.repeat(base["ee"][:, :, :, :1], nmax, axis=3))
@@ -24,14 +25,17 @@ if __name__ == "__main__":
                     p["hallo"] = np.asfortranarray(np.repeat(base["eeo"][:, :, :, :1], nmax, axis=3))
             rec = Recursion(*objects_from(p, irec, 20), device=0)
             t0 = time.perf_counter(); rec.update_hamiltonian(); t_set = time.perf_counter() - t0
-            rec.recur_b()
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter(); rec.recur_b(); ts.append(time.perf_counter() - t0)
-            tm = rec.timing()
+            res = {}
+            for octet in (0, 1):
+                rec.set_option("s5_octet", octet)
+                rec.recur_b()
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); rec.recur_b(); ts.append(time.perf_counter() - t0)
+                res[octet] = (1e3 * min(ts), int(rec.timing()["octet_launches"]))
             if ref is None:
                 ref = rec.a_b.copy()
             dev = float(np.abs(rec.a_b - ref).max() / np.abs(ref).max())
-            print("hoh=%d kk=%d nmax=%-5d set_hamiltonian %.2f ms   recur_b %.1f ms (H|psi> %.1f ms in %d launches)   max deviation from nmax=0: %.1e"
-                  % (hoh, kk, nmax, 1e3 * t_set, 1e3 * min(ts), tm["hop_ms"], tm["hop_launches"], dev), flush=True)
+            print("hoh=%d kk=%d sites=%d nmax=%-5d set_hamiltonian %.2f ms   recur_b %.1f ms per-atom groups, %.1f ms over chains (%d of the launches)   max deviation from nmax=0: %.1e"
+                  % (hoh, kk, len(irec), nmax, 1e3 * t_set, res[0][0], res[1][0], res[1][1], dev), flush=True)
             rec.close()
