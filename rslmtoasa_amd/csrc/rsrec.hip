@@ -65,6 +65,8 @@ struct rsrec_handle {
     hipEvent_t ev_green[2] = {nullptr, nullptr};
     hipStream_t side_stream = nullptr;     // B_{n+1} reduction + eigen-solve of level n, concurrent with H u_{n+1} of level n + 1 (u-scheme)
     hipEvent_t ev_orth = nullptr, ev_bred = nullptr;
+    hipStream_t oct_stream = nullptr;      // the chain-octet launch of a level's H|psi> beside its main launch (disjoint outputs)
+    hipEvent_t ev_oct_in = nullptr, ev_oct_out = nullptr;
     size_t p2_slot = 0;                    // doubles per slot of d_partial2 (slot 1: the side stream's presum)
     std::string err;
     // lattice (host copies for the region search + device tables)
@@ -378,6 +380,9 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     for (hipEvent_t e : h->ev_green) if (e) (void)hipEventDestroy(e);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->oct_stream) (void)hipStreamDestroy(h->oct_stream);
+    if (h->ev_oct_in) (void)hipEventDestroy(h->ev_oct_in);
+    if (h->ev_oct_out) (void)hipEventDestroy(h->ev_oct_out);
     if (h->ev_orth) (void)hipEventDestroy(h->ev_orth);
     if (h->ev_bred) (void)hipEventDestroy(h->ev_bred);
     delete h;
@@ -1022,7 +1027,7 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
     // Atoms with their own operator blocks (an impurity region: classes 0 .. nmax - 1, the first nmax groups of the class-sorted list of all
     // atoms, one atom + seven padding tiles each): once EVERY chain of the batch is on that list their groups are formed over 8 chains
     // instead -- the chains share the atom's fragments -- by a launch of their own; the main launch skips them.
-    bool octets = false;
+    bool octets = false, oct_aside = false;
     if (!multi && one < 0 && h->opt_s5_octet > 0 && h->nmax >= h->opt_s5_octet && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.nchains >= 2 && SD.level >= 0 &&
         SD.level < (int)E->level_sat.size() && E->level_sat[SD.level] == SD.nchains && op.ntau == h->nmax + h->ntype &&
         (double)GROUP * (double)(h->kk + 1) * BLD * 8.0 < 4294967296.0 && (int)E->sat_runs.size() >= h->nmax &&
@@ -1031,15 +1036,26 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
         SpmmDims SO = SD;
         SO.sat_base = E->sat_base; SO.run_lo = 0; SO.run_hi = h->nmax;
         const dim3 go((unsigned)((h->nmax + S5_WG_GROUPS - 1) / S5_WG_GROUPS), (unsigned)((SD.nchains + GROUP - 1) / GROUP));
-        k_spmm5<TWO, false, true><<<go, S5_WG_GROUPS * 128, 0, h->stream>>>(SO, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau,
-                                                                          0, nullptr, 1, epi);
+        // beside the main launch, on a stream of its own (the two write disjoint blocks of `out`): alone it is a launch of a few hundred
+        // groups with the whole GPU to itself
+        hipStream_t so = h->stream;
+        if (h->opt_side && !h->oct_stream && !h->capturing &&
+            (hipStreamCreateWithFlags(&h->oct_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_oct_in, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&h->ev_oct_out, hipEventDisableTiming) != hipSuccess)) { h->oct_stream = nullptr; (void)hipGetLastError(); }
+        if (h->opt_side && h->oct_stream && h->ev_oct_in && h->ev_oct_out && hipEventRecord(h->ev_oct_in, h->stream) == hipSuccess &&
+            hipStreamWaitEvent(h->oct_stream, h->ev_oct_in, 0) == hipSuccess) { so = h->oct_stream; oct_aside = true; }
+        k_spmm5<TWO, false, true><<<go, S5_WG_GROUPS * 128, 0, so>>>(SO, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau,
+                                                                   0, nullptr, 1, epi);
+        if (oct_aside) (void)hipEventRecord(h->ev_oct_out, h->oct_stream);
         // the main launch takes the rest of that list as ONE run (every chain is on it), so that its XCD chunks are cut from what it serves
         SD.sat_base = E->sat_base; SD.run_lo = h->nmax; SD.run_hi = E->sat_runs.back().hi;
         octets = true;
         h->n_octet_launch++;
     }
-    if (!multi) launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, extra, ntau, epi, one);
-    else {
+    if (!multi) {
+        launch_s5_one<TWO>(h, grid, SD, order, cum, iz, op, set, in, out, in2, extra, ntau, epi, one);
+        if (oct_aside) (void)hipStreamWaitEvent(h->stream, h->ev_oct_out, 0);            // the level goes on when both launches are done
+    } else {
         // class runs worth workgroups of their own: at least two groups per workgroup of a full persistent launch over the chains on the list
         SD.sat_base = E->sat_base;
         const long min_groups = h->opt_s5_run_min > 0 ? h->opt_s5_run_min : std::max<long>(64, 2L * h->n_cu * 8 / std::max(1, E->level_sat[SD.level]));
