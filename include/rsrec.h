@@ -251,16 +251,25 @@ int rsrec_comm_destroy(rsrec_t *h);
 /* key/value knobs (defaults in brackets; everything but "batch" and "kernels" exists for A/B measurements and tests):
  *   "batch"      chains advanced together per launch [0 = auto: up to 64, bounded by free device memory]
  *   "kernels"    0 = auto, 1 = FP64 VALU kernel set (the reference's layout and operation order; any stencil), 2 = matrix-core set [0]
- *   "spmm5"      SpMM of the matrix-core set: 0 = small-launch kernel k_spmm4<4> (LayoutRM vectors), 1 = by launch size (k_spmm5 on CI
- *                vectors from 4096 groups per launch; always for hoh and local-axis runs), 2 = always k_spmm5 [1]
- *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u> [1]
+ *   "spmm5"      SpMM of the matrix-core set: 0 = small-launch kernel k_spmm4<4> (LayoutRM vectors) whenever it applies, 1 = by launch size
+ *                (k_spmm5 on CI vectors from 4096 groups per launch; always for hoh and local-axis runs), 2 = always k_spmm5 [2]
+ *   "side_stream" reduction + eigen-solve of B_{n+1} on a second HIP stream, concurrent with the next H|u>; the chain-octet launch beside
+ *                the main H|psi> launch [1]
+ *   "graph"      the level loop of a block-Lanczos call as one HIP graph, replayed while lattice, seeds, depth, buffers and options stay
+ *                the same: 0 = never, 1 = calls of up to 8 chains, 2 = every single-batch call [1]
  *   "nblk"       workgroups per chain / 2 of the reduction-bearing kernels [0 = by batch size]
+ *   "orth3"      k_mfma_orth3: 1 = one 512-register wave per SIMD (tables in registers), 2 = two waves per SIMD (tables in LDS) [1]
+ *   "cheb_fused" Chebyshev step inside the SpMM epilogue (H psi never written): 0 / 1 [1]
  *   "chain_fold" chains per k_spmm5 workgroup [1],  "s5_cap" cap on k_spmm5 workgroups per chain [0 = none],
- *   "s5_lds"     k_spmm5 with the operator fragments in LDS for operators with one class of atoms: 0 = never, 1 = whenever it applies [1]
+ *   "s5_lds"     k_spmm5 with the operator fragments in LDS: 0 = never, 1 = operators with one class of atoms, whenever their stream fits,
+ *                2 = also operators with several classes (one run of groups per class of the class-sorted atom list; slower) [1]
+ *   "s5_queue"   the LDS form as persistent workgroups (one per CU) with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
+ *                workgroups, 2 = always [1];  "s5_waves" waves per persistent workgroup, 8 or 4 [8];  "s5_run_min" smallest class run
+ *                (groups) that gets LDS workgroups of its own under s5_lds = 2 [0 = by launch size]
  *   "s5_octet"   atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS of the batch (they then share
  *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [64]
- *   "s5_queue"   that form as 256 persistent workgroups with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
- *                workgroups, 2 = always [1] */
+ *   "s5_host_emit" 1 = swizzle k_spmm5's operator streams on the host instead of assembling them on the device (cross-check) [0]
+ *   "kubo_lchunk" rsrec_kubo_moments: left vectors held on the device at a time [0 = as many as fit] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
 /* Timing of the last recursion call, measured with HIP events on the engine's own stream:
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,
