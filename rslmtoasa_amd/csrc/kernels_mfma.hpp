@@ -208,6 +208,9 @@ struct SpmmDims {
     //                workgroups, the kernel's XCD mapping) hold the stream of class run_tau[r] and take the groups [run_glo[r], run_ghi[r]).
     int sat_base = 0, run_lo = 0, run_hi = 0, nskip = 0, skip_lo[4] = {0, 0, 0, 0}, skip_hi[4] = {0, 0, 0, 0};
     int nruns = 0, run_tau[4] = {0, 0, 0, 0}, run_glo[4] = {0, 0, 0, 0}, run_ghi[4] = {0, 0, 0, 0}, run_row0[5] = {0, 0, 0, 0, 0};
+    // atoms with their own operator blocks (classes 0 .. nmax - 1) served by the chain-octet launch (k_spmm5<., ., true>: group g = atom g for
+    // 8 chains, whatever list a chain is on): skip_pa = 1 makes every other launch pass over their groups
+    int skip_pa = 0;
 };
 
 // ---- reductions of the 36x36 real partials ----------------------------------------------------------------------------

@@ -622,7 +622,8 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     const int ob = D.obase[(chain / D.cpo) * D.nlev + D.level];
     const int* __restrict__ order = order_all + (size_t)(chain / D.cpo) * D.ostride + ob;
     const bool on_full_list = D.sat_base > 0 && ob == D.sat_base;          // the class-sorted list of all atoms
-    if (run_hi > 0) {                                                       // one class run of that list (its stream is what this workgroup holds in LDS)
+    if constexpr (OCT) ngroups = D.nmax;                                    // group g = atom g (no list), for the 8 chains from `chain` on
+    else if (run_hi > 0) {                                                       // one class run of that list (its stream is what this workgroup holds in LDS)
         if (!on_full_list) continue;
         order += (size_t)run_lo * GROUP;
         ngroups = run_hi - run_lo;
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         int vatom[GROUP], tile_blk[GROUP];                  // OCT: block index of tile t's own atom seen from chain c0's vectors; its neighbour blocks' shift
         int my_rem_atom, rem_blk = 0;
         if constexpr (OCT) {
-            const int a0 = grp[0];                          // the group's one atom (a class run of per-atom blocks: one atom, seven padding entries)
+            const int a0 = g;                               // the group's one atom
 #pragma unroll
             for (int t = 0; t < GROUP; ++t) {
                 const bool ok = a0 >= 0 && chain + t < D.nchains;
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             my_rem_atom = my_rem_atom >= 0 ? my_rem_atom : zero_block;
         }
         const int first = atom[0];
+        if (!OCT && D.skip_pa && first < D.nmax) continue;  // an atom with its own operator blocks: the chain-octet launch serves it
         const int tau = first < D.nmax ? first : D.nmax + izp[first];
         const int* __restrict__ M = meta + (size_t)tau * Spmm5Operator::META;
         const char* __restrict__ fr = LDSA ? reinterpret_cast<const char*>(s5_lds) : reinterpret_cast<const char*>(frag + ((size_t)tau * 2 + sig) * ntr * S5_TRIPLE);

@@ -1024,17 +1024,17 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
     // so it is not the default; the parity tests run it)
     const bool multi = one < 0 && h->opt_s5_lds >= 2 && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.level >= 0 && SD.level < (int)E->level_sat.size() &&
                        E->level_sat[SD.level] > 0 && op.ntau == h->nmax + h->ntype && (grid.x >= (unsigned)std::max(16, h->n_cu / 16 * 16) || h->opt_s5_queue >= 2) && (size_t)op.ntr * S5_TRIPLE * sizeof(double) <= (s5_prepare(h), h->s5_lds_limit);
-    // Atoms with their own operator blocks (an impurity region: classes 0 .. nmax - 1, the first nmax groups of the class-sorted list of all
-    // atoms, one atom + seven padding tiles each): once EVERY chain of the batch is on that list their groups are formed over 8 chains
-    // instead -- the chains share the atom's fragments -- by a launch of their own; the main launch skips them.
+    // Atoms with their own operator blocks (an impurity region: classes 0 .. nmax - 1) are one-tile groups of their own in a chain's lists.
+    // From `s5_octet` such atoms on, and once at least half of the (atom, chain) pairs of the batch are inside their chains' regions, a
+    // launch of its own forms their groups over 8 CHAINS instead -- the chains share the atom's fragments; an atom outside a chain's
+    // region has no active neighbour there and comes out as the zeros it already is -- and the main launch passes over them.
     bool octets = false, oct_aside = false;
-    if (!multi && one < 0 && h->opt_s5_octet > 0 && h->nmax >= h->opt_s5_octet && !extra && E && E->sat_base > 0 && SD.cpo == 1 && SD.nchains >= 2 && SD.level >= 0 &&
-        SD.level < (int)E->level_sat.size() && E->level_sat[SD.level] == SD.nchains && op.ntau == h->nmax + h->ntype &&
-        (double)GROUP * (double)(h->kk + 1) * BLD * 8.0 < 4294967296.0 && (int)E->sat_runs.size() >= h->nmax &&
-        E->sat_runs[0].tau == 0 && E->sat_runs[0].lo == 0 && E->sat_runs[h->nmax - 1].tau == h->nmax - 1 && E->sat_runs[h->nmax - 1].hi == h->nmax) {
-        // (the list is sorted by class, per-atom classes first: groups 0 .. nmax - 1 are those atoms, one each)
+    double pa_pairs = 0.0;
+    if (h->cur_level_groups && SD.level >= 0 && (size_t)(SD.level + 1) * op.ntau <= h->cur_level_groups->size() && op.ntau == h->nmax + h->ntype)
+        for (int t = 0; t < h->nmax; ++t) pa_pairs += (*h->cur_level_groups)[(size_t)SD.level * op.ntau + t];
+    if (!multi && one < 0 && h->opt_s5_octet > 0 && h->nmax >= h->opt_s5_octet && !extra && E && SD.cpo == 1 && SD.nchains >= 2 && op.ntau == h->nmax + h->ntype &&
+        2.0 * pa_pairs >= (double)h->nmax * SD.nchains && (double)GROUP * (double)(h->kk + 1) * BLD * 8.0 < 4294967296.0) {
         SpmmDims SO = SD;
-        SO.sat_base = E->sat_base; SO.run_lo = 0; SO.run_hi = h->nmax;
         const dim3 go((unsigned)((h->nmax + S5_WG_GROUPS - 1) / S5_WG_GROUPS), (unsigned)((SD.nchains + GROUP - 1) / GROUP));
         // beside the main launch, on a stream of its own (the two write disjoint blocks of `out`): alone it is a launch of a few hundred
         // groups with the whole GPU to itself
@@ -1047,8 +1047,13 @@ void launch_s5(rsrec_t* h, dim3 grid, const SpmmDims& SD0, const int* order, con
         k_spmm5<TWO, false, true><<<go, S5_WG_GROUPS * 128, 0, so>>>(SO, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau,
                                                                    0, nullptr, 1, epi);
         if (oct_aside) (void)hipEventRecord(h->ev_oct_out, h->oct_stream);
-        // the main launch takes the rest of that list as ONE run (every chain is on it), so that its XCD chunks are cut from what it serves
-        SD.sat_base = E->sat_base; SD.run_lo = h->nmax; SD.run_hi = E->sat_runs.back().hi;
+        const bool all_sat = E->sat_base > 0 && SD.level < (int)E->level_sat.size() && E->level_sat[SD.level] == SD.nchains && (int)E->sat_runs.size() >= h->nmax &&
+                             E->sat_runs[0].tau == 0 && E->sat_runs[0].lo == 0 && E->sat_runs[h->nmax - 1].tau == h->nmax - 1 && E->sat_runs[h->nmax - 1].hi == h->nmax;
+        if (all_sat) {
+            // every chain is on the class-sorted list of all atoms, whose first nmax groups are those atoms: the main launch takes the rest
+            // of that list as ONE run, so that its XCD chunks are cut from what it serves
+            SD.sat_base = E->sat_base; SD.run_lo = h->nmax; SD.run_hi = E->sat_runs.back().hi;
+        } else SD.skip_pa = 1;
         octets = true;
         h->n_octet_launch++;
     }
