@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Cost of per-atom operator blocks (`hall`, the first nmax atoms; hamiltonian.f90:1618): the same periodic bcc cell with nmax = 0 ... 1000
 atoms carrying their own (identical) copies of the stencil, with their groups formed per atom (s5_octet = 0) and over 8 chains (s5_octet = 1).
-Block Lanczos, LL = 20.   tools/time_nmax.py [sites]"""
+Block Lanczos, LL = 20.   tools/time_nmax.py [sites] [inside]   (inside: the recursion sites are the first atoms of the impurity region itself,
+as in the reference's impurity runs, instead of being spread over the cell)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,8 @@ if __name__ == "__main__":
     for hoh in (False, True):
         base = supercell_problem(dims, hoh=hoh)
         kk = base["nn"].shape[0]
-        irec = spread_sites(kk, int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+        nsites = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+        irec = np.arange(1, nsites + 1, dtype=np.int32) if len(sys.argv) > 2 else spread_sites(kk, nsites)
         ref = None
         for nmax in (0, 15, 32, 64, 200, 1000):
             p = dict(base, nmax=nmax)
