@@ -14,6 +14,7 @@
 // 1024 to 256, which is what lets the 15-fold neighbour re-reads of psi blocks hit the XCD's 4 MiB L2 instead of the fabric
 // (measured before: 52 GB fetched per launch for 5.7 GB algorithmic, profiles/r01_mfma_pmc_summary.txt).
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <vector>
@@ -58,11 +59,17 @@ struct Spmm4Operator {
         if (po == pi) return hr;
         return po == 0 ? -hi : hi;
     }
+    // 1: the spin-flip quadrants of the block are zero (a spin-diagonal block), 0: not.  Branch-free over the nine contiguous complex numbers
+    // of a quadrant column (an impurity region of 1000 atoms hands over 32 000 blocks per call): the bit patterns are OR-ed, the sign
+    // bit dropped at the end (-0.0 is zero, NaN is not -- as `!= 0.0` has it)
     static int pattern_of(const double* blk) {
-        for (int c = 0; c < 18; ++c)
-            for (int r = 0; r < 18; ++r)
-                if ((r < 9) != (c < 9) && (blk[2 * (r + 18 * c)] != 0.0 || blk[2 * (r + 18 * c) + 1] != 0.0)) return 0;
-        return 1;
+        unsigned long long acc = 0;
+        for (int c = 0; c < 18; ++c) {
+            unsigned long long w[18];
+            memcpy(w, blk + 2 * (18 * c + (c < 9 ? 9 : 0)), sizeof w);
+            for (int i = 0; i < 18; ++i) acc |= w[i];
+        }
+        return (acc & 0x7fffffffffffffffULL) ? 0 : 1;
     }
     static void swizzle(const double* blk, double* out) {
         for (int q = 0; q < 9; ++q)

@@ -291,7 +291,10 @@ struct Spmm5Operator {
         const int nt = nmax + ntype, nset = hoh ? 2 : 1, nfs = nslots_lat + 1;
         const size_t B = 2 * (size_t)BLK;
         std::vector<const double*> blk((size_t)nset * nt * nfs, nullptr);
-        std::vector<double> tmp((size_t)(hoh ? nt * nfs : 0) * B, 0.0);
+        // set 1 on the host: -(h o)_s (+ 1 on-site) per slot when the streams are swizzled here; with device assembly only the extra on-site
+        // slot e_nu + l.s of every class is formed here (for the block structure), the rest stays a descriptor
+        const size_t tmp_per = dev ? 1 : (size_t)nfs;
+        std::vector<double> tmp((size_t)(hoh ? nt : 0) * tmp_per * B, 0.0);
         std::vector<S5Desc> desc(dev ? (size_t)nset * nt * nfs : 0, S5Desc{nullptr, nullptr, 1.0, 0.0});
         for (int tau = 0; tau < nt; ++tau)
             for (int s = 0; s < nslots_lat; ++s) {
@@ -303,7 +306,7 @@ struct Spmm5Operator {
                     const double* ho = (tau < nmax ? hallo : eeo) + off;
                     if (dev) { blk[((size_t)nt + tau) * nfs + s] = ho; desc[((size_t)nt + tau) * nfs + s] = S5Desc{(tau < nmax ? dev[3] : dev[2]) + off, nullptr, -1.0, s == 0 ? 1.0 : 0.0}; }
                     else {
-                        double* d = tmp.data() + B * ((size_t)tau * nfs + s);
+                        double* d = tmp.data() + B * ((size_t)tau * tmp_per + s);
                         for (size_t e = 0; e < B; ++e) d[e] = -ho[e];
                         if (s == 0) for (int q = 0; q < NB; ++q) d[2 * (q + NB * q)] += 1.0;
                         blk[((size_t)nt + tau) * nfs + s] = d;
@@ -313,7 +316,7 @@ struct Spmm5Operator {
         if (hoh)
             for (int tau = 0; tau < nt; ++tau) {
                 const int ty = tau < nmax ? iz0[tau] : tau - nmax;
-                double* d = tmp.data() + B * ((size_t)tau * nfs + nslots_lat);
+                double* d = tmp.data() + B * ((size_t)tau * tmp_per + (dev ? 0 : nslots_lat));
                 for (size_t e = 0; e < B; ++e) d[e] = enim[B * ty + e] + lsham[B * ty + e];
                 blk[((size_t)nt + tau) * nfs + nslots_lat] = d;
                 if (dev) desc[((size_t)nt + tau) * nfs + nslots_lat] = S5Desc{dev[4] + B * ty, dev[5] + B * ty, 1.0, 0.0};
