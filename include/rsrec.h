@@ -266,6 +266,8 @@ int rsrec_comm_destroy(rsrec_t *h);
  *   "s5_queue"   the LDS form as persistent workgroups (one per CU) with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
  *                workgroups, 2 = always [1];  "s5_waves" waves per persistent workgroup, 8 or 4 [8];  "s5_run_min" smallest class run
  *                (groups) that gets LDS workgroups of its own under s5_lds = 2 [0 = by launch size]
+ *   "s5_spin_xcd" persistent form on collinear operators: 1 = even XCDs serve output spin 0 and odd XCDs spin 1 (an XCD's L2 then holds one
+ *                spin half of the neighbour blocks; the round-2 default), 0 = both spins on every XCD (2-4 % faster, round 3) [0]
  *   "s5_octet"   atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS of the batch (they then share
  *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [64]
  *   "s5_host_emit" 1 = swizzle k_spmm5's operator streams on the host instead of assembling them on the device (cross-check) [0]

@@ -115,6 +115,7 @@ struct rsrec_handle {
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
+    long opt_s5_spin_xcd = 0;    // persistent k_spmm5 on collinear operators: 1 = even XCDs serve output spin 0, odd XCDs spin 1; 0 = both spins on every XCD
     long opt_s5_octet = 64;      // atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS instead of one atom + 7 padding tiles (0: never)
     long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
@@ -413,6 +414,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
     else if (!strcmp(key, "s5_octet")) h->opt_s5_octet = value;
+    else if (!strcmp(key, "s5_spin_xcd")) h->opt_s5_spin_xcd = value;
     else if (!strcmp(key, "s5_run_min")) h->opt_s5_run_min = value;
     else return fail(h, RSREC_ERR_ARG, "unknown option '%s'", key);
     return RSREC_OK;
@@ -985,7 +987,10 @@ void launch_s5_one(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, 
     s5_prepare(h);
     const size_t lds_limit = h->s5_lds_limit;
     if (want && one >= 0 && !extra && lds_bytes <= lds_limit) {
-        const int spin_by_xcd = op.spin_mixing ? 0 : 1;
+        // both output spins on every XCD (workgroup rows alternate between them, an XCD sweeps an eighth of the list) also for collinear
+        // operators: the split "even XCDs spin 0, odd XCDs spin 1" of round 2 (an XCD's L2 then holds one spin half of the neighbour blocks)
+        // measured 2-4 % slower on every workload at the end of round 3 (tools/ab_spin_xcd.sh); option s5_spin_xcd = 1 brings it back
+        const int spin_by_xcd = (op.spin_mixing || !h->opt_s5_spin_xcd) ? 0 : 1;
         const unsigned row = spin_by_xcd ? 8 : 16;
         dim3 g2(std::max(row, (grid.x + row - 1) / row * row), grid.y);
         int* queue = nullptr;
@@ -1360,7 +1365,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
                                           (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
                                           (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
-                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet};
+                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet, (uintptr_t)h->opt_s5_spin_xcd};
             for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
             if (!h->graph_exec || key != h->graph_key) {
                 if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
