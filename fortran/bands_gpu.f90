@@ -33,7 +33,8 @@ module bands_gpu_mod
    use timer_mod, only: g_timer
    use string_mod, only: fmt
    use rsrec_binding
-   use recursion_gpu_mod, only: rsrec_gpu_context, rsrec_gpu_block_resident
+   use rsrec_context_mod, only: rsrec_gpu_context, rsrec_env_flag
+   use recursion_gpu_mod, only: rsrec_gpu_block_resident
 #ifdef USE_MPI
    use mpi
 #endif
@@ -77,6 +78,7 @@ contains
       obj%control => green_obj%dos%recursion%lattice%control
       obj%recursion => green_obj%dos%recursion
       call obj%restore_to_default()
+      if (rsrec_env_flag('RSREC_HOST_LDOS')) obj%device_ldos = .false.   ! (hosts that cannot reach the member: fortran/shadow/)
    end function gpu_constructor
 
    !> `g0` must exist before an inherited routine reads it

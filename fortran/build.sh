@@ -13,7 +13,7 @@ FC="${FC:-/opt/rocm/bin/amdflang}"
 MKLDIR="${MKLDIR:-/opt/conda/lib}"
 if [ ! -f "$OUT/librslmto_ref.a" ]; then echo "oracle/_ref not built: skipping Fortran drop-in build"; exit 0; fi
 FFLAGS="-cpp -O2 -fopenmp -J$OUT/mod -I$OUT/mod"
-for f in rsrec_binding recursion_gpu green_gpu bands_gpu hamiltonian_gpu lattice_cells; do
+for f in rsrec_binding rsrec_context recursion_gpu green_gpu bands_gpu hamiltonian_gpu lattice_cells; do
   (cd "$OUT/obj" && "$FC" $FFLAGS -c "$HERE/$f.f90" -o "$OUT/obj/$f.o")
 done
 # the test programs (tests/fortran/): the reference's workflows with the drop-in types behind them
@@ -21,11 +21,11 @@ for f in scf_gpu_driver kubo_gpu_driver nncal_check; do
   (cd "$OUT/obj" && "$FC" $FFLAGS -c "$ROOT/tests/fortran/$f.f90" -o "$OUT/obj/$f.o")
 done
 "$FC" "$OUT/obj/nncal_check.o" "$OUT/obj/lattice_cells.o" "$OUT/librslmto_ref.a" -fopenmp -L"$MKLDIR" -lmkl_rt -Wl,-rpath,"$MKLDIR" -o "$OUT/nncal_check.x"
-"$FC" "$OUT/obj/scf_gpu_driver.o" "$OUT/obj/bands_gpu.o" "$OUT/obj/green_gpu.o" "$OUT/obj/hamiltonian_gpu.o" "$OUT/obj/recursion_gpu.o" "$OUT/obj/lattice_cells.o" "$OUT/obj/rsrec_binding.o" "$OUT/librslmto_ref.a" \
+"$FC" "$OUT/obj/scf_gpu_driver.o" "$OUT/obj/bands_gpu.o" "$OUT/obj/green_gpu.o" "$OUT/obj/hamiltonian_gpu.o" "$OUT/obj/recursion_gpu.o" "$OUT/obj/lattice_cells.o" "$OUT/obj/rsrec_context.o" "$OUT/obj/rsrec_binding.o" "$OUT/librslmto_ref.a" \
   -fopenmp -L"$MKLDIR" -lmkl_rt -Wl,-rpath,"$MKLDIR" \
   -L"$ROOT/rslmtoasa_amd" -lrsrec -Wl,-rpath,'$ORIGIN/../../rslmtoasa_amd' -Wl,-rpath,/opt/rocm/lib \
   -o "$OUT/rslmto_gpu.x"
-"$FC" "$OUT/obj/kubo_gpu_driver.o" "$OUT/obj/recursion_gpu.o" "$OUT/obj/rsrec_binding.o" "$OUT/librslmto_ref.a" \
+"$FC" "$OUT/obj/kubo_gpu_driver.o" "$OUT/obj/recursion_gpu.o" "$OUT/obj/rsrec_context.o" "$OUT/obj/rsrec_binding.o" "$OUT/librslmto_ref.a" \
   -fopenmp -L"$MKLDIR" -lmkl_rt -Wl,-rpath,"$MKLDIR" \
   -L"$ROOT/rslmtoasa_amd" -lrsrec -Wl,-rpath,'$ORIGIN/../../rslmtoasa_amd' -Wl,-rpath,/opt/rocm/lib \
   -o "$OUT/kubo_gpu.x"

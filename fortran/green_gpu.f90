@@ -23,7 +23,7 @@ module green_gpu_mod
    use logger_mod, only: g_logger
    use timer_mod, only: g_timer
    use rsrec_binding
-   use recursion_gpu_mod, only: rsrec_gpu_context
+   use rsrec_context_mod, only: rsrec_gpu_context, rsrec_env_flag
    implicit none
 
    private
@@ -35,6 +35,7 @@ module green_gpu_mod
       !> device LDOS stage from the coefficients the recursion left on the GPU) then never produces `g0` at all.
       logical :: defer_g0 = .false.
       logical :: g0_stale = .false.
+      logical :: fetching = .false.   ! set by fetch_g0 around its own block_green call: the one caller that makes a deferred g0
    contains
       procedure :: bgreen => gpu_bgreen
       procedure :: block_green => gpu_block_green
@@ -60,6 +61,7 @@ contains
       obj%lattice => dos_obj%recursion%lattice
       obj%control => dos_obj%recursion%lattice%control
       call obj%restore_to_default()
+      if (rsrec_env_flag('RSREC_DEFER_G0')) obj%defer_g0 = .true.    ! (hosts that cannot reach the member: fortran/shadow/)
    end function gpu_constructor
 
    !> Replaces green.f90:1191-1339 (same interface; `g_out` is zeroed and the energy range ie_start .. ie_start+ie_len-1 filled).
@@ -113,9 +115,9 @@ contains
       real(rp), allocatable, target :: ene(:), ai(:, :, :), bi(:, :, :)
       complex(rp), allocatable, target :: ab(:, :, :, :), bs(:, :, :, :), gt(:, :, :, :)
 
-      if (this%defer_g0 .and. .not. this%g0_stale) then
-         this%g0_stale = .true.                               ! produced by fetch_g0 when somebody reads g0
-         return
+      if (this%defer_g0 .and. .not. this%fetching) then
+         this%g0_stale = .true.                               ! produced by fetch_g0 when somebody reads g0; repeated calls without a
+         return                                               ! reader in between (block_green + calculate_fermi, DOS-only flows) stay free
       end if
       this%g0_stale = .false.
       ll = this%control%lld
@@ -161,7 +163,9 @@ contains
    subroutine gpu_fetch_g0(this)
       class(green_gpu), intent(inout) :: this
       if (.not. this%g0_stale) return
-      call this%block_green()                                ! g0_stale is set: this call does the work
+      this%fetching = .true.
+      call this%block_green()                                ! the one call that does the work
+      this%fetching = .false.
    end subroutine gpu_fetch_g0
 
    !> Replaces green.f90:1030-1108: g0 of the sites of this rank from the Chebyshev moments.  The side effect of the reference

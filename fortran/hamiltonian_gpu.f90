@@ -18,11 +18,12 @@
 module hamiltonian_gpu_mod
    use, intrinsic :: iso_c_binding
    use hamiltonian_mod
+   use charge_mod, only: charge
    use precision_mod, only: rp
    use math_mod, only: i_unit, cone, czero
    use logger_mod, only: g_logger
    use timer_mod, only: g_timer
-   use recursion_gpu_mod, only: rsrec_gpu_context
+   use rsrec_context_mod, only: rsrec_gpu_context, rsrec_env_flag
    use rsrec_binding
    implicit none
    private
@@ -37,7 +38,26 @@ module hamiltonian_gpu_mod
       procedure :: build_locham => gpu_build_locham
    end type hamiltonian_gpu
 
+   interface hamiltonian_gpu
+      procedure :: gpu_constructor
+   end interface hamiltonian_gpu
+
 contains
+
+   !> Same construction as hamiltonian.f90:129-139 (pointers, restore_to_default, build_from_file), on the extended object itself.
+   !> RSREC_HOST_HAM set in the environment: device_assembly = .false. (the switch for hosts that cannot reach the member -- the
+   !> reference's unmodified calculation.f90 behind fortran/shadow/hamiltonian_mod.f90).
+   function gpu_constructor(charge_obj) result(obj)
+      type(hamiltonian_gpu) :: obj
+      type(charge), target, intent(in) :: charge_obj
+
+      obj%charge => charge_obj
+      obj%lattice => charge_obj%lattice
+      obj%control => charge_obj%lattice%control
+      call obj%restore_to_default()
+      call obj%build_from_file()
+      if (rsrec_env_flag('RSREC_HOST_HAM')) obj%device_assembly = .false.
+   end function gpu_constructor
 
    !> Collect what chbar_nc left for class atom `ia` into column `icls` of the device call's inputs; the neighbour types as :1586-1597.
    subroutine collect_class(this, ia, icls, nr, hm, ty)

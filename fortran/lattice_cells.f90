@@ -18,6 +18,7 @@
 module lattice_cells_mod
    use precision_mod, only: rp
    use lattice_mod
+   use control_mod, only: control
    implicit none
    private
    public :: lattice_cells
@@ -29,7 +30,21 @@ module lattice_cells_mod
       procedure :: nncal => nncal_cells
    end type lattice_cells
 
+   interface lattice_cells
+      procedure :: cells_constructor
+   end interface lattice_cells
+
 contains
+
+   !> Same construction as lattice.f90:361-370 (control pointer, restore_to_default, build_from_file), on the extended object itself.
+   function cells_constructor(control_obj) result(obj)
+      type(lattice_cells) :: obj
+      type(control), target, intent(in) :: control_obj
+
+      obj%control => control_obj
+      call obj%restore_to_default()
+      call obj%build_from_file()
+   end function cells_constructor
 
    subroutine nncal_cells(this, ct, crd, ndim, nat, izp, nn, nd, nm, ngbr, ntot)
       class(lattice_cells), intent(inout) :: this

@@ -32,6 +32,7 @@ module recursion_gpu_mod
    use logger_mod, only: g_logger
    use timer_mod, only: g_timer
    use rsrec_binding
+   use rsrec_context_mod
    implicit none
 
    private
@@ -59,8 +60,7 @@ module recursion_gpu_mod
 
    public :: rsrec_gpu_shutdown, rsrec_gpu_context, rsrec_gpu_block_resident
 
-   !> the per-process device context (lazy)
-   type(c_ptr), save :: g_handle = c_null_ptr
+   !> (the per-process device context g_handle lives in rsrec_context_mod; re-exported above for the hosts that used it from here)
    !> number of sites whose block coefficients the last driver call left on the device (0: none -- another driver ran since, or the
    !> coefficients there are not the ones in a_b / b2_b, as after a local-axis run): the input of the device LDOS stage
    integer, save :: g_block_resident = 0
@@ -80,19 +80,6 @@ contains
       call obj%restore_to_default()
    end function gpu_constructor
 
-   !> The per-process device context, created on first use (shared with green_gpu_mod).
-   function rsrec_gpu_context() result(handle)
-      type(c_ptr) :: handle
-      integer(c_int) :: rc, ndev
-      if (.not. c_associated(g_handle)) then
-         ndev = rsrec_device_count()
-         if (ndev <= 0) call g_logger%fatal('recursion_gpu: no usable GPU (librsrec has no CPU fallback)', __FILE__, __LINE__)
-         rc = rsrec_create(g_handle, int(mod(rank, ndev), c_int))
-         if (rc /= 0) call g_logger%fatal('recursion_gpu: rsrec_create failed', __FILE__, __LINE__)
-      end if
-      handle = g_handle
-   end function rsrec_gpu_context
-
    !> Sites of this rank whose a_b / b2_b (as recur_b produced them) are also resident on the device; 0 if they are not.
    function rsrec_gpu_block_resident() result(n)
       integer :: n
@@ -111,15 +98,10 @@ contains
    subroutine sync_device(this, upload_lattice)
       class(recursion_gpu), intent(inout), target :: this
       logical, intent(in) :: upload_lattice
-      integer(c_int) :: rc, ndev, hoh_i
-      type(c_ptr) :: p_hall, p_hallo
+      integer(c_int) :: rc, hoh_i
+      type(c_ptr) :: p_hall, p_hallo, ctx
 
-      if (.not. c_associated(g_handle)) then
-         ndev = rsrec_device_count()
-         if (ndev <= 0) call g_logger%fatal('recursion_gpu: no usable GPU (librsrec has no CPU fallback)', __FILE__, __LINE__)
-         rc = rsrec_create(g_handle, int(mod(rank, ndev), c_int))
-         if (rc /= 0) call g_logger%fatal('recursion_gpu: rsrec_create failed', __FILE__, __LINE__)
-      end if
+      ctx = rsrec_gpu_context()                                  ! creates g_handle on first use
       if (upload_lattice) then
          rc = rsrec_set_lattice(g_handle, int(this%lattice%kk, c_int), int(size(this%lattice%nn, 2), c_int), &
                                 c_loc(this%lattice%nn), c_loc(this%lattice%iz), int(this%lattice%nmax, c_int), &
@@ -168,13 +150,6 @@ contains
                                  c_loc(this%hamiltonian%ee_glob), c_loc(this%hamiltonian%lsham), p_eeo, p_enim, p_hall, p_hallo)
       call check(rc, 'rsrec_set_hamiltonian')
    end subroutine sync_device_global_frame
-
-   !> Release the device context (optional; call once before MPI_FINALIZE).
-   subroutine rsrec_gpu_shutdown()
-      integer(c_int) :: rc
-      if (c_associated(g_handle)) rc = rsrec_destroy(g_handle)
-      g_handle = c_null_ptr
-   end subroutine rsrec_gpu_shutdown
 
    !---------------------------------------------------------------------------
    !> Block recursion for the sites of this rank (replaces recursion.f90:1807-1866)

@@ -1,0 +1,16 @@
+!------------------------------------------------------------------------------
+! green_mod -- SHADOW of the reference's module of the same name (source/green.f90), for the zero-edit drop-in build.
+!
+! The reference's green.f90 is compiled unchanged but under another module name (-Dgreen_mod=green_ref_mod; its sources are
+! compiled with -cpp already), the GPU type of fortran/ extends the reference type from there, and THIS module hands that extended type
+! out under the reference's names: every `use green_mod` in the reference -- calculation.f90, self.f90, main.f90 and the modules
+! between -- then declares and constructs `type(green)` objects that ARE `type(green_gpu)`, with no line of the reference edited.
+! The reference module exports nothing but the type and its generic constructor (`private` + `type, public`), and a rename on
+! use association carries both.  Recipe: fortran/build_dropin.sh; INTEGRATION.md section 2.
+!------------------------------------------------------------------------------
+module green_mod
+   use green_gpu_mod, only: green => green_gpu
+   implicit none
+   private
+   public :: green
+end module green_mod

@@ -54,6 +54,9 @@
 
 namespace rsrec {
 
+#ifndef RSREC_S5_KSPLIT_PROBE
+#define RSREC_S5_KSPLIT_PROBE 0
+#endif
 #ifndef S5_WG_GROUPS
 #define S5_WG_GROUPS 4   // groups of 8 atoms per workgroup (x 2 spin waves each): 4 -> 512 threads
 #endif
@@ -121,6 +124,7 @@ struct Spmm5Operator {
     size_t desc_bytes = 0;
     std::vector<signed char> sched_sig;   // block structure (absent / spin-diagonal / spin-mixing per block) the uploaded schedule was built for
     int sched_dims[3] = {0, 0, 0};
+    int sched_epoch = 0;         // counts rebuilt schedules: whatever holds the schedule's shape by value (a captured graph) is keyed by it
     int ntau = 0, nslots = 0, have_o = 0, ntr = 0, spin_mixing = 0;   // spin_mixing: some regular (hopping) block has a spin-flip part
     static constexpr int META = 2 + S5_MAXENT + S5_ENTPAD;
     struct Entry { const double* blk; int col; int flip; };        // blk == nullptr: null entry (zero fragments, reads the zero block)
@@ -190,6 +194,7 @@ struct Spmm5Operator {
         if (nslots_lat + 1 > S4_MAXSLOTS) return "too many neighbour slots for the spmm5 kernel";
         const bool same = !sched_out && d_meta && sched_dims[0] == nslots_lat && sched_dims[1] == ntau_ && sched_dims[2] == nset && sched_sig == kind;
         if (same) return nullptr;
+        ++sched_epoch;
         ntau = ntau_; nslots = nslots_lat; have_o = nset > 1 ? 1 : 0; spin_mixing = 0;
         const int nfs = nslots + 1, null_col = nslots + 1;
         std::vector<std::vector<std::pair<int, int>>> sched((size_t)nset * ntau);
@@ -435,8 +440,16 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
                                               const int (&atom)[GROUP] /*padding -> zero block*/, int rem_sel /*per lane: tile (atom of the group) of its remainder column*/,
                                               int ncol, int sig, int l4,
                                               unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8,
-                                              const int (&tile_blk)[GROUP], int rem_blk /*per lane: tile_blk of its remainder tile*/) {
+                                              const int (&tile_blk)[GROUP], int rem_blk /*per lane: tile_blk of its remainder tile*/, int kpart = 0) {
     int left = meta[0];
+    int ebase = 0, tbase = 0;
+    bool first = true;
+#if RSREC_S5_KSPLIT_PROBE
+    // TIMING PROBE ONLY (results invalid): a task is one PERIOD-ALIGNED part of a group's stream -- part 0 the first 27 steps (10 entries),
+    // part 1 the rest -- so that twice as many waves work on one group and an XCD has half as many atoms in flight
+    if (kpart == 0) left = min(left, 27);
+    else { left -= 27; ebase = 10; tbase = 9; first = false; }
+#endif
     if (left <= 0) return;
     const bool extras = TWO && meta[1] != 0;
     // the schedule and the neighbour table through the constant address space: scalar loads (a vector load + readfirstlane here put a
@@ -445,14 +458,12 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
     const S5_CONST int* nbr = (const S5_CONST int*)nbr5;
     S5Ent E0, E1;
     int raw[GROUP];
-    int code_cur = codes[0], code_nxt = codes[1];
+    int code_cur = codes[ebase], code_nxt = codes[ebase + 1];
     auto load_idx = [&](int col) {
 #pragma unroll
         for (int t = 0; t < GROUP; ++t) raw[t] = nbr[(size_t)ncol * atom[t] + col];
     };
     load_idx(code_cur & 255);
-    int ebase = 0, tbase = 0;
-    bool first = true;
     unsigned vlane_main = lane_main, vlane_z = lane_z, vlane16 = lane16, vlane8 = lane8;
     // entry j (its indices are in raw, its code in code_cur) becomes addressable; the indices of entry j + 1 are requested
     auto open_entry = [&](int j, S5Ent& E) {
@@ -692,10 +703,15 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     // in-order vmcnt queue and every operand wait of the first steps then waits for it as well -- 19 % slower)
     // (round 3: the pull issued right after the group's last operands were consumed, its round trip under the result stores: +1.5 %)
     for (;; g += gstep) {
+        int kpart = 0;
         if (dynamic) {
             int gi = 0;
             if (lane == 0) gi = atomicAdd(ctr, 1);
-            g = glo + __builtin_amdgcn_readfirstlane(gi);
+            gi = __builtin_amdgcn_readfirstlane(gi);
+#if RSREC_S5_KSPLIT_PROBE
+            kpart = gi & 1; gi >>= 1;
+#endif
+            g = glo + gi;
         }
         if (g >= gend) break;
         if (skipping) {                                     // groups of a class run that a launch with that class's stream in LDS serves
@@ -739,7 +755,10 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         for (int t = 0; t < 9; ++t) { acc.m[t] = (double4_t){0, 0, 0, 0}; acc.r[t] = 0.0; }
 
         if constexpr (OCT) s5_run_stream<TWO, LDSA, true>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8, tile_blk, rem_blk);
-        else s5_run_stream<TWO, LDSA>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8, tile_blk, rem_blk);
+        else s5_run_stream<TWO, LDSA>(acc, M, fr, fh, inb, in2b, nbr, atom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8, tile_blk, rem_blk, kpart);
+#if RSREC_S5_KSPLIT_PROBE
+        if (kpart) continue;                                // (probe: one part stores)
+#endif
 
         // 16x16x4 result register j, lane (l15, l4): real-form row l4 + 4 j of spin sig = (part j & 1, m = l4 + 4 (j >> 1)), column l15:
         // registers (2 p, 2 p + 1) are the real and imaginary part of element (m = 4 p + l4, c) -> one 16-byte store in the CI

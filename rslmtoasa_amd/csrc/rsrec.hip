@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -100,6 +101,7 @@ struct rsrec_handle {
     int asm_nslots[2] = {0, 0}, asm_ncls[2] = {0, 0}, asm_hoh[2] = {0, 0};
     int n_octet_launch = 0;      // launches of the last call that formed the groups of per-atom-block atoms over 8 chains (k_spmm5<., false, true>)
     int n_asm_reused = 0;        // block arrays the last rsrec_set_hamiltonian took from those device copies (0..4)
+    long n_asm_calls = 0, n_ldos_calls = 0, n_recursion_calls = 0;   // life-time counters of the handle (RSREC_REPORT)
     Spmm5Operator s5_la; int s5_la_ok = 0;   // operator tables of local-axis runs: H without the on-site l.s term, which comes per chain
     DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
@@ -344,6 +346,19 @@ extern "C" int rsrec_device_count(void) {
     return n;
 }
 
+// RSREC_REPORT set in the environment: one line of the handle's counters when the process exits -- the evidence a host that cannot
+// ask (the reference's unmodified main program behind the shadow modules, fortran/build_dropin.sh) leaves in its log that its
+// operator was assembled on the device and taken from there, and that the LDOS stage ran there.  Host-side counters only: no HIP call
+// is made from the exit handler.
+static rsrec_handle* g_report_handle = nullptr;
+static void report_at_exit() {
+    const rsrec_handle* h = g_report_handle;
+    if (!h) return;
+    std::printf("rsrec report: library_calls=%ld device_assemblies=%ld operator_arrays_from_device=%d device_ldos_calls=%ld\n", h->n_recursion_calls, h->n_asm_calls,
+                h->n_asm_reused, h->n_ldos_calls);
+    std::fflush(stdout);
+}
+
 extern "C" int rsrec_create(rsrec_t** out, int device) {
     if (!out) return RSREC_ERR_ARG;
     *out = nullptr;
@@ -356,11 +371,17 @@ extern "C" int rsrec_create(rsrec_t** out, int device) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RSREC_ERR_DEVICE; }
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     *out = h;
+    if (getenv("RSREC_REPORT") && !g_report_handle) {
+        static bool registered = false;
+        if (!registered) { registered = std::atexit(report_at_exit) == 0; }
+        g_report_handle = h;
+    }
     return RSREC_OK;
 }
 
 extern "C" int rsrec_destroy(rsrec_t* h) {
     if (!h) return RSREC_ERR_ARG;
+    if (g_report_handle == h) { report_at_exit(); g_report_handle = nullptr; }
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)rsrec_comm_destroy(h);
@@ -440,7 +461,16 @@ extern "C" void rsrec_site_partition(int rank, int nprocs, int nsites, int* star
 }
 
 // cached regions (device order lists) of lattice epochs that ended; the stream is idle between calls
+static void release_graph(rsrec_t* h) {
+    if (h->graph_exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    h->graph_key.clear();
+}
+
+// cached regions (device order lists) of lattice epochs that ended; the stream is idle between calls.  The captured level loop holds
+// the region lists, the lattice tables and their dimensions BY VALUE: it goes with them (a new RegionEntry / hipMalloc of the same
+// size commonly returns the old address, so pointers alone cannot tell a new lattice from the old one)
 static void release_regions(rsrec_t* h) {
+    release_graph(h);
     if (!h->region_cache.empty()) (void)hipDeviceSynchronize();
     for (auto* e : h->region_cache) { e->order.release(); e->cum.release(); delete e; }
     h->region_cache.clear();
@@ -633,6 +663,7 @@ extern "C" int rsrec_assemble_blocks(rsrec_t* h, int part, int ncls, int nslots,
         for (size_t q = 0; q < (size_t)ncls * nslots; ++q)
             if (nbr_type[q] < 0 || nbr_type[q] > ntype) return fail(h, RSREC_ERR_ARG, "rsrec_assemble_blocks: nbr_type[%zu]=%d outside 0..%d", q, nbr_type[q], ntype);
     HIPCK(h, hipSetDevice(h->device));
+    h->n_asm_calls++;
     h->asm_nslots[part] = h->asm_ncls[part] = 0;          // nothing valid while this runs
     const size_t nblk = (size_t)ncls * nslots, hm_bytes = nblk * 4 * 81 * 16, ty_bytes = nblk * 4, ob_bytes = hoh ? (size_t)ntype * 324 * 16 : 0;
     const size_t ty_off = (hm_bytes + 255) / 256 * 256, ob_off = ty_off + (ty_bytes + 255) / 256 * 256;
@@ -892,6 +923,7 @@ void reset_timing(rsrec_t* h) {
     h->n_hop_launch = h->n_atom_steps = h->n_block_mult = h->n_hop_mfma_flop = h->n_req_flop = 0;
     h->n_octet_launch = 0;
     h->ev_used = 0;
+    h->n_recursion_calls++;          // (every timed entry point: recursions, Green / LDOS stages, Kubo moments)
 }
 
 double ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -1160,6 +1192,11 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     const Spmm5Operator& OP = rot ? h->s5_la : h->s5_op;
     const int la_fps = S5_HEAD_DOUBLES;
     if (rot) HIPCK(h, h->d_la_extra.reserve((size_t)std::min(nchains, 64) * ntau * la_fps * sizeof(double)));
+    // the coefficients of ALL chains of the call stay on the device (resident input of rsrec_pack_diag / rsrec_block_ldos): reserved before
+    // the batch is planned from the free memory
+    h->res_kind = 0;
+    HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
+    HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -1175,10 +1212,6 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         HIPCK(h, hipEventCreateWithFlags(&h->ev_bred, hipEventDisableTiming));
     }
     HIPCK(h, h->d_frags.reserve((size_t)B * 3 * 27 * 64 * sizeof(double)));
-    // the coefficients of ALL chains of the call stay on the device (resident input of rsrec_pack_diag / rsrec_block_ldos)
-    h->res_kind = 0;
-    HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
-    HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_bmats.reserve((size_t)B * 2 * BLK * sizeof(double2)));
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
@@ -1365,7 +1398,9 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
                                           (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
                                           (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
-                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet, (uintptr_t)h->opt_s5_spin_xcd};
+                                          (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet, (uintptr_t)h->opt_s5_spin_xcd,
+                                          (uintptr_t)h->lattice_epoch, (uintptr_t)OP.sched_epoch, (uintptr_t)h->nslots, (uintptr_t)h->nmax, (uintptr_t)h->ntype, (uintptr_t)h->hslots,
+                                          (uintptr_t)h->opt_s5_waves, (uintptr_t)h->opt_batch, (uintptr_t)B, (uintptr_t)h->opt_kernels, (uintptr_t)h->n_cu};
             for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
             if (!h->graph_exec || key != h->graph_key) {
                 if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -1903,6 +1938,7 @@ extern "C" int rsrec_block_ldos(rsrec_t* h, int nen, const double* ene, double e
     const int n = h->res_n, lld = h->res_lld;
     if (site_offset + n > nsites_total) return fail(h, RSREC_ERR_ARG, "rsrec_block_ldos: sites %d..%d outside 1..%d", site_offset + 1, site_offset + n, nsites_total);
     HIPCK(h, hipSetDevice(h->device));
+    h->n_ldos_calls++;
     const size_t cel = (size_t)n * lld * BLK;
     HIPCK(h, h->d_bsqrt.reserve(cel * sizeof(double2)));
     HIPCK(h, h->d_term.reserve(2 * (size_t)n * BLK * sizeof(double) + 2 * (size_t)n * sizeof(double)));
@@ -2016,6 +2052,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     const int nvec = MFMA ? (hoh ? 5 : 4) : (hoh ? 4 : 3);
     const int ci = use_kp ? 1 : 0;                              // vectors of this call are CI (else LayoutRM / LayoutCM)
     if (MFMA && !use_kp) { rc = ensure_s4(h); if (rc) return rc; }
+    // the moments of ALL chains of the call stay on the device (rsrec_pack_moments): reserved BEFORE the batch is planned from the free
+    // memory, so a call over many sites (nrec ~ kk) sizes its vectors around them instead of failing behind them
+    h->res_kind = 0;
+    HIPCK(h, h->d_mu.reserve((size_t)nsites * nmom * BLK * sizeof(double2)));
     BatchPlan bp;
     rc = plan_batch(h, nsites, nvec, velems / 2, bp);
     if (rc) return rc;
@@ -2031,8 +2071,6 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     }
     const bool side = h->opt_side && h->side_stream;     // moment reduction of level t under the SpMM of level t + 1 (it feeds nothing on the device)
     bool red_pending = false;
-    h->res_kind = 0;
-    HIPCK(h, h->d_mu.reserve((size_t)nsites * nmom * BLK * sizeof(double2)));      // the moments of ALL chains of the call stay on the device (rsrec_pack_moments)
     HIPCK(h, h->d_status.reserve(64));
     HIPCK(h, h->d_seed.reserve((size_t)B * nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)B * (nseed + 1) * sizeof(double2)));

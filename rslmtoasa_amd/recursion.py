@@ -276,8 +276,12 @@ class Recursion:
         if isinstance(buf, int):
             self._check(self._L.rsrec_allreduce_sum(self._h, C.c_void_p(buf), int(n)))
         else:
-            assert buf.dtype == np.float64 and buf.flags["C_CONTIGUOUS"] or buf.flags["F_CONTIGUOUS"]
-            self._check(self._L.rsrec_allreduce_sum(self._h, C.c_void_p(buf.ctypes.data), buf.size))
+            # the images this mirror reduces are float64 (diagonals, LDOS) or complex128 (a_b, mu_n): a complex array counts as 2 doubles per element
+            if buf.dtype not in (np.float64, np.complex128):
+                raise TypeError("allreduce_sum: float64 or complex128 arrays only, got %s" % buf.dtype)
+            if not (buf.flags["C_CONTIGUOUS"] or buf.flags["F_CONTIGUOUS"]):
+                raise ValueError("allreduce_sum: the array must be contiguous (it is reduced in place)")
+            self._check(self._L.rsrec_allreduce_sum(self._h, C.c_void_p(buf.ctypes.data), buf.nbytes // 8))
 
     def recur_b_ij(self):
         """Four chains per atom pair, seeds (psi_i +- psi_j)/sqrt2 and (psi_i +- i psi_j)/sqrt2 (recursion.f90:1655-1800)."""

@@ -19,6 +19,24 @@ PAIR_CASES = ["sc_4x4x8_block_ij", "sc_4x4x8_cheb_ij", "sc_4x4x8_cheb_ij_hoh"]
 RTOL = 1e-10
 
 
+def require_built(path):
+    """The compiled-reference drivers under oracle/_ref are built in the build container and travel to the GPU box with the snapshot.
+    Where a GPU is visible their absence is a FAILURE (fifteen boundary tests must not vanish from a green run); without a GPU
+    (these are -m gpu tests, so this only happens in a development shell) it is a skip."""
+    import pytest
+    if os.path.exists(path):
+        return
+    msg = "%s not built (oracle/build_ref.sh + fortran/build.sh in the build container; the binaries travel with the snapshot)" % os.path.relpath(path, os.path.dirname(GOLD))
+    try:
+        from rslmtoasa_amd import _lib
+        on_gpu_box = _lib.lib().rsrec_device_count() > 0
+    except Exception:
+        on_gpu_box = False
+    if on_gpu_box:
+        pytest.fail(msg + " -- missing on a box that has the GPU")
+    pytest.skip(msg)
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False) as z:
         d = {k: z[k] for k in z.files}

@@ -26,6 +26,7 @@ def load_module(path, name):
 class Args:
     def __init__(self, **kw):
         self.sites, self.cells, self.lld, self.hoh, self.spin_mixing, self.no_positions, self.recur, self.workload = 64, 22, 50, False, False, False, "block", "bcc"
+        self.cells_given = False
         self.__dict__.update(kw)
 
 
@@ -42,6 +43,19 @@ def test_workloads_and_reference_flop_count():
     assert list(Wi["irec"][:15]) == list(range(1, 16)) and len(set(Wi["irec"].tolist())) == 128 and Wi["irec"].max() <= 4152      # the impurity region first, no site twice
     m, a = b.algorithmic_work(Wi["nn"], 1, 49, True)
     assert m > 2 * a > 0                                            # hoh: two passes per level
+
+
+def test_default_workload_is_the_north_star_cell(monkeypatch):
+    """`python bench.py` with no flags measures the cell BASELINE.json's target is quoted on: 46^3 = 97 336 atoms, 64 sites, LL = 50."""
+    b = load_module(os.path.join(ROOT, "bench.py"), "bench_mod3")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse_args()
+    assert (a.cells, a.sites, a.lld, a.recur, a.workload, a.gpus) == (46, 64, 50, "block", "bcc", 1) and not a.cells_given
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "kubo"])
+    assert b.parse_args().cells == 20
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--cells", "22"])
+    a = b.parse_args()
+    assert a.cells == 22 and a.cells_given
 
 
 def test_periodic_fcc_table_of_the_kubo_workload():

@@ -13,6 +13,7 @@ import subprocess
 
 import pytest
 
+from helpers import require_built
 from oracle.make_fixtures import patch_namelist
 from rslmtoasa_amd._proc import run_with_unlimited_stack
 
@@ -47,8 +48,7 @@ def fortran_float(tok):
 def test_scf_workflow_with_gpu_recursion(name, tmp_path):
     case = MANIFEST[name]
     exe = os.path.join(os.path.dirname(EXE), case.get("exe", "rslmto_gpu.x"))    # kubo_gpu.x: the conductivity post-processing workflow
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/%s not built (needs the reference sources: build container only)" % os.path.basename(exe))
+    require_built(exe)
     work = tmp_path / "run"
     shutil.copytree(os.path.join(SCF, case["inputs"]), work)
     inp = work / "input.nml"
@@ -108,8 +108,7 @@ def test_density_of_states_without_g0(name, tmp_path):
     self.f90:821-833) with `bands_gpu` + `green_gpu%defer_g0`: dtot / dosia / dosial come from rsrec_block_ldos on the coefficients
     the recursion left on the device, and g0 (13 MB per site) is never produced.  Checked against the same flow with the reference's
     own host reduction over a downloaded g0: the three files the reference writes must agree to the printed digits."""
-    if not os.path.exists(EXE):
-        pytest.skip("oracle/_ref/rslmto_gpu.x not built (needs the reference sources: build container only)")
+    require_built(EXE)
     case = MANIFEST[name]
     outs = {}
     # (the device run also brings up the library's own communicator through a file -- one rank: the box has one GPU)

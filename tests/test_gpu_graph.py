@@ -56,6 +56,67 @@ def test_graph_recaptures_when_depth_or_seeds_change(oracle_lib):
     rec.close()
 
 
+def test_graph_recaptures_when_the_lattice_changes_on_the_same_handle():
+    """Same handle, same kk / seeds / depth, another neighbour table (a vacancy: every reference to one atom removed) and then another
+    nmax: the captured graph holds the region lists, grids and lattice dimensions by value, and a freed region entry or table commonly
+    comes back at the same address -- the graph must go with the lattice, not be recognised by pointers (round-3 advisor finding)."""
+    p = supercell_problem((6, 6, 6))
+    sites = np.array([1, 100, 216], dtype=np.int32)
+    rec = Recursion(*objects_from(p, sites, 12), device=0)
+
+    def both_paths():
+        out = []
+        for graph in (1, 1, 0):
+            rec.set_option("graph", graph)
+            rec.a_b[:] = 0
+            rec.recur_b()
+            out.append((rec.a_b.copy(), rec.b2_b.copy()))
+        assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1])
+        assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
+        return out[2]
+
+    a0, _ = both_paths()
+    nn = p["nn"].copy()
+    nn[:, 1:][nn[:, 1:] == 50] = 0                       # atom 50 becomes unreachable: same kk, same columns, other regions
+    rec.lattice.nn = nn
+    rec.update_lattice()
+    rec.update_hamiltonian()
+    a1, _ = both_paths()
+    assert np.abs(a1 - a0).max() > 1e-6
+    # per-atom blocks for the first 3 atoms (copies of the stencil): other operator classes, same tables otherwise
+    rec.lattice.nmax = 3
+    rec.hamiltonian.hall = np.repeat(np.asarray(p["ee"])[:, :, :, :1], 3, axis=3) * 1.1
+    rec.update_lattice()
+    rec.update_hamiltonian()
+    a2, _ = both_paths()
+    assert np.abs(a2 - a1).max() > 1e-6
+    for key, val in (("s5_waves", 4), ("batch", 2)):     # options whose value a captured launch holds
+        rec.set_option(key, val)
+        both_paths()
+    rec.close()
+
+
+def test_allreduce_sum_counts_complex_images_in_doubles():
+    """One-rank communicator = identity; what is checked is the marshalling: a complex128 F-ordered image is 2 doubles per element, and
+    anything that is not float64 / complex128 is refused (round-3 advisor finding: operator precedence let every F-ordered array through)."""
+    p = supercell_problem((4, 4, 8))
+    rec = Recursion(*objects_from(p, np.array([1], dtype=np.int32), 5), device=0)
+    try:
+        rec.comm_init(0, 1, Recursion.comm_unique_id())
+    except Exception as e:                                # RCCL not loadable on this box: nothing to marshal into
+        rec.close()
+        pytest.fail("library communicator could not be created: %s" % e)
+    img = np.asfortranarray((np.arange(18 * 18 * 4).reshape(18, 18, 4) * (1 + 2j)).astype(np.complex128))
+    ref = img.copy()
+    rec.allreduce_sum(img)
+    assert np.array_equal(img, ref)
+    with pytest.raises(TypeError):
+        rec.allreduce_sum(np.zeros((4, 4), np.float32, order="F"))
+    with pytest.raises(ValueError):
+        rec.allreduce_sum(np.zeros((8, 8))[::2])
+    rec.close()
+
+
 @pytest.mark.parametrize("name", ["B2FeCo_block_hoh", "fccCu001_block_hoh"])
 def test_graph_on_the_reference_cases(name):
     """The reference's own impurity / surface SCF cases (2 sites, per-atom hall blocks resp. 3 types): graph path vs golden coefficients."""

@@ -12,7 +12,7 @@ import shutil
 import numpy as np
 import pytest
 
-from helpers import RTOL, load_golden
+from helpers import RTOL, load_golden, require_built
 from oracle.make_fixtures import ORBITAL_CASES, patch_namelist
 from rslmtoasa_amd._proc import run_with_unlimited_stack
 from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion
@@ -59,8 +59,7 @@ def test_fortran_override_reproduces_the_reference_file(tmp_path):
     """kubo_gpu.x (the reference's modules + type(recursion_gpu)) in the orbital-moment workflow: unit 50 against the compiled
     reference's file.  Column 1 (E - E_F) to its printed digits; the trace columns are rounding noise in both."""
     exe = os.path.join(ROOT, "oracle", "_ref", "kubo_gpu.x")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kubo_gpu.x not built (needs the reference sources: build container only)")
+    require_built(exe)
     z = load_golden("fccPt_orbital")
     work = tmp_path / "run"
     shutil.copytree(os.path.join(ROOT, "tests", "golden", "scf", "inputs", "conductivity_fccPt"), work)

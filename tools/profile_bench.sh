@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline object cites: a kernel-trace/stats pass and separate PMC passes
 # (FETCH_SIZE, WRITE_SIZE, TCC hit/miss -- one counter set per pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
-# Usage (on the GPU box): [BENCH_EXTRA="--cells 46"] tools/profile_bench.sh <tag> [workload_key]
+# Usage (on the GPU box): [BENCH_EXTRA="--cells 22"] tools/profile_bench.sh <tag> [workload_key]
 #   -> gpurun_out/prof_<tag>/{stats,pmc_*}, gpurun_out/prof_<tag>/summary.txt, gpurun_out/prof_<tag>/traffic.json
 set -e
 TAG=${1:-run}
@@ -17,7 +17,7 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_$N.log
 done
 if [ -n "$KEY" ]; then
-  PROFILE_NAME=${PROFILE_NAME:-r02_${TAG}_rocprof_summary.txt} python3 $ROOT/tools/summarize_pmc.py $OUT --traffic-key $KEY --traffic-out $OUT/traffic.json > $OUT/summary.txt
+  PROFILE_NAME=${PROFILE_NAME:-r04_${TAG}_rocprof_summary.txt} python3 $ROOT/tools/summarize_pmc.py $OUT --traffic-key $KEY --traffic-out $OUT/traffic.json > $OUT/summary.txt
 else
   python3 $ROOT/tools/summarize_pmc.py $OUT > $OUT/summary.txt
 fi

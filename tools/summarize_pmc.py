@@ -11,6 +11,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_pmc_sha import kernel_sha  # noqa: E402
+
 out = sys.argv[1]
 key = tout = None
 if "--traffic-key" in sys.argv:
@@ -56,6 +59,20 @@ if key:
     tab = {}
     if os.path.exists(tout):
         tab = json.load(open(tout))
-    tab[key] = {k: {"bytes_per_launch": v, "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_bench.sh)" % os.environ.get("PROFILE_NAME", os.path.basename(out))}
+    sha = kernel_sha()
+    tab[key] = {k: {"bytes_per_launch": v, "kernel_sha": sha,
+                    "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_bench.sh; sources %s)" % (os.environ.get("PROFILE_NAME", os.path.basename(out)), sha)}
                 for k, v in table.items()}
     json.dump(tab, open(tout, "w"), indent=1, sort_keys=True)
+# the bench line of the stats pass with the traffic of THIS run's PMC passes in place of the table lookup
+bl = os.path.join(out, "bench_stats.json")
+if os.path.exists(bl) and "k_spmm5" in table:
+    try:
+        line = [l for l in open(bl).read().splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        d["roofline"]["traffic"] = table["k_spmm5"]
+        d["roofline"]["traffic_source"] = "measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/profile_bench.sh), sources %s" % kernel_sha()
+        d["roofline"]["traffic_per_algorithmic"] = None
+        json.dump(d, open(os.path.join(out, "bench_measured.json"), "w"))
+    except Exception as e:  # noqa
+        print("# bench_measured.json not written: %r" % (e,))
