@@ -2,9 +2,16 @@
 (fortran/recursion_gpu.f90) swapped in, against the reference's committed expected values
 (tests/scf/references/*/ref.json and tests/regression/bccFe_lanczos/Fe.nml.ref, copied as data to tests/golden/scf/).
 
-The binary oracle/_ref/rslmto_gpu.x is linked in the build container by fortran/build.sh from the reference's object
-code + our Fortran shim + librsrec.so; it travels to the GPU box with oracle/_ref/.  Comparison rule = the reference's
-own (tests/run_test.py:201-219): a value fails only if BOTH abs and rel differences exceed the tolerance."""
+Two builds of the boundary, both linked in the build container and travelling to the GPU box with oracle/_ref/:
+  * "dropin": oracle/_ref/rslmto_dropin.x (fortran/build_dropin.sh) -- the reference's OWN main program, linked from its unmodified
+    main.f90 / calculation.f90 / self.f90 ... with the GPU types behind the reference's module names (fortran/shadow/): the zero-edit
+    drop-in BASELINE.json's north_star asks for.  It runs every case of the manifest, the conductivity post-processing included
+    (`post_processing = 'conductivity'` is the reference's own branch, calculation.f90:206).
+  * "driver": oracle/_ref/rslmto_gpu.x / kubo_gpu.x (fortran/build.sh) -- the reference's object code + a driver program of ours that
+    declares the GPU types explicitly (the edited-declarations integration; also the host of the flows the reference's program has no
+    switch for: LDOS only, the library's own communicator).
+Comparison rule = the reference's own (tests/run_test.py:201-219): a value fails only if BOTH abs and rel differences exceed the
+tolerance."""
 import json
 import os
 import re
@@ -20,6 +27,7 @@ from rslmtoasa_amd._proc import run_with_unlimited_stack
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCF = os.path.join(ROOT, "tests", "golden", "scf")
 EXE = os.path.join(ROOT, "oracle", "_ref", "rslmto_gpu.x")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "rslmto_dropin.x")
 MANIFEST = json.load(open(os.path.join(SCF, "manifest.json")))
 
 pytestmark = pytest.mark.gpu
@@ -44,22 +52,27 @@ def fortran_float(tok):
     return float(m.group(1) + "e" + m.group(2)) if m else float(tok.replace("D", "E").replace("d", "e"))
 
 
+@pytest.mark.parametrize("build", ["dropin", "driver"])
 @pytest.mark.parametrize("name", sorted(MANIFEST))
-def test_scf_workflow_with_gpu_recursion(name, tmp_path):
+def test_scf_workflow_with_gpu_recursion(name, build, tmp_path):
     case = MANIFEST[name]
-    exe = os.path.join(os.path.dirname(EXE), case.get("exe", "rslmto_gpu.x"))    # kubo_gpu.x: the conductivity post-processing workflow
+    exe = DROPIN if build == "dropin" else os.path.join(os.path.dirname(EXE), case.get("exe", "rslmto_gpu.x"))    # kubo_gpu.x: the conductivity post-processing workflow
     require_built(exe)
     work = tmp_path / "run"
     shutil.copytree(os.path.join(SCF, case["inputs"]), work)
     inp = work / "input.nml"
     inp.write_text(patch_namelist(inp.read_text(), case["patch"]))
-    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8"}, timeout=1500, scrub=False)   # the child drives the GPU itself
+    # RSREC_REPORT: the library prints its life-time counters when the process exits (the reference's main program cannot be asked)
+    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8", "RSREC_REPORT": "1"}, timeout=1500, scrub=False)   # the child drives the GPU itself
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     assert "fatal" not in log.lower(), log[-3000:]                      # tests/run_test.py:119-131
+    m = re.search(r"rsrec report: library_calls=(\d+)", log)
+    assert m and int(m.group(1)) >= 1, log[-2000:]                       # the GPU library did the work (there is no other path, but say so)
     if "exe" in case:
-        assert "compute_moments_stochastic wall time" in log
-        print("\n".join(l for l in log.splitlines() if "compute_moments_stochastic wall time" in l))
+        if build == "driver":
+            assert "compute_moments_stochastic wall time" in log
+            print("\n".join(l for l in log.splitlines() if "compute_moments_stochastic wall time" in l))
     elif "'block'" in str(case["patch"]):
         # block recursions: the Green function (green%bgreen) also ran on the GPU (fortran/green_gpu.f90); its timer region is
         # listed in the reference's own timing report
