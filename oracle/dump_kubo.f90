@@ -26,7 +26,8 @@ program dump_kubo
    type(hamiltonian), target :: hamiltonian_obj
    type(recursion), target :: recursion_obj
    type(mix), target :: mix_obj
-   integer :: i, u, hoh_i, nslots, elen, estat
+   integer :: i, k, u, hoh_i, nslots, elen, estat, version
+   real(rp), allocatable :: rng(:, :)
    integer(8) :: t0, t1, rate
    real(rp) :: a, b
    character(len=8) :: envv
@@ -99,7 +100,23 @@ program dump_kubo
    hoh_i = 0
    if (hamiltonian_obj%hoh) hoh_i = 1
    open (newunit=u, file='kubo.bin', access='stream', form='unformatted', status='replace')
-   write (u) int(z'4b55424f'), 2
+   ! version 3 (cond_calctype = 'random_vec', recursion.f90:1101-1140): the random numbers of every vector.  The routine draws them as
+   ! `call random_seed()` + kk x `call random_number(rng)` per vector (:1106, :1130-1136); this toolchain's random_seed() without
+   ! arguments RESETS the generator to its default state (amdflang / flang runtime -- checked: the same numbers in every process and after
+   ! every call), so replaying the same calls here yields exactly the numbers the routine used.  (With a runtime that seeds from the
+   ! clock this record would be meaningless; the fixture generator checks that the moments computed from it reproduce mu_nm_stochastic.)
+   version = 2
+   if (trim(control_obj%cond_calctype) == 'random_vec') then
+      version = 3
+      allocate (rng(lattice_obj%kk, size(recursion_obj%mu_nm_stochastic, 5)))
+      do i = 1, size(rng, 2)
+         call random_seed()
+         do k = 1, lattice_obj%kk
+            call random_number(rng(k, i))
+         end do
+      end do
+   end if
+   write (u) int(z'4b55424f'), version
    write (u) lattice_obj%kk, size(lattice_obj%nn, 2), lattice_obj%nmax, lattice_obj%ntype, control_obj%cond_ll, control_obj%nsp, hoh_i, nslots, &
       size(recursion_obj%mu_nm_stochastic, 5)
    write (u) a, b
@@ -116,5 +133,6 @@ program dump_kubo
    write (u) hamiltonian_obj%vo_b
    write (u) recursion_obj%mu_nm_stochastic
    write (u) lattice_obj%cr(1:3, 1:lattice_obj%kk), lattice_obj%alat          ! version 2: positions (units of alat) and alat
+   if (version >= 3) write (u) rng
    close (u)
 end program dump_kubo

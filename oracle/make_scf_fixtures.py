@@ -185,8 +185,11 @@ def generated_conductivity(exe):
     shutil.copy(os.path.join(src, "Pt.nml"), os.path.join(dst, "Pt.nml"))
     for fn in ("input.nml", "Pt.nml"):
         os.chmod(os.path.join(dst, fn), 0o644)
-    for hoh in (False, True):
-        name = "Generated_conductivity_fccPt_spin" + ("_hoh" if hoh else "")
+    for hoh, rnd in ((False, False), (True, False), (False, True)):
+        # (the third, round 4: cond_calctype = 'random_vec', recursion.f90:1101-1140 -- one random-phase vector over all atoms.  This
+        # toolchain's random_seed() resets the generator, so the compiled reference and the GPU host, both amdflang programs, draw the
+        # same numbers and the branch can be compared end to end)
+        name = "Generated_conductivity_fccPt_spin" + ("_hoh" if hoh else "") + ("_random_vec" if rnd else "")
         # Compared: fort.123 = (E - E_F, Re, Im) of the energy-resolved integrand  sum_nm Gamma_nm(E) tr mu_nm  that
         # calculate_conductivity_tensor writes BEFORE it integrates (conductivity.f90:317) -- a deterministic function of the moments.
         # NOT compared: Pt_cond.out / cond_total.out.  Their Fermi-weighted Simpson integrals (simpson_f, math.f90:1607-1621) run
@@ -197,6 +200,8 @@ def generated_conductivity(exe):
         # 1.025866e-01; hoh -1.002817e-04 / 5.598055e-04 / 6.179803e-02, checked here).
         patch = {"control": {"nsp": "2", "recur": "'chebyshev'", "lld": "50", "linear_out": "'spin'", "linear_in": "'charge'"}, "self": {"nstep": "1"},
                  "hamiltonian": {"hoh": ".true." if hoh else ".false."}}
+        if rnd:
+            patch["control"].update(cond_calctype="'random_vec'", random_vec_num="1")
         work = _run_reference(exe, dst, patch)
         try:
             rows = open(os.path.join(work, "fort.123")).read().splitlines()
@@ -211,4 +216,12 @@ def generated_conductivity(exe):
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    if sys.argv[1:] == ["conductivity"]:      # only (re)generate the conductivity cases and merge them into the manifest
+        sys.path.insert(0, ROOT)
+        man = json.load(open(os.path.join(OUT, "manifest.json")))
+        man.update(generated_conductivity(os.path.join(ROOT, "oracle", "_ref", "rslmto_ref.x")))
+        json.dump(man, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+        print("manifest now holds", len(man), "cases")
+    else:
+        main()

@@ -42,6 +42,14 @@ def _f(a, dtype):
     return np.asfortranarray(np.asarray(a, dtype=dtype))
 
 
+class DiagonalizationError(RuntimeError):
+    """The reference's fatal exit of crecal_b (recursion.f90:1942): zheev fails on the NaN matrix a Krylov breakdown leaves behind.
+    .a_b / .b2_b hold what was computed (NaN from the failing level on for the chains that broke down)."""
+    def __init__(self, msg, a_b, b2_b):
+        super().__init__(msg)
+        self.a_b, self.b2_b = a_b, b2_b
+
+
 class Oracle:
     """Holds one problem (lattice tables + Hamiltonian blocks) for the CPU oracle."""
 
@@ -66,17 +74,21 @@ class Oracle:
         self.P = _Problem(self.kk, self.nncols, self.nmax, self.ntype, self.nslots, self.hoh, self.nsp,
                           ptr("nn"), ptr("iz"), ptr("ee"), ptr("lsham"), ptr("eeo"), ptr("enim"), ptr("hall"), ptr("hallo"))
 
-    def block_lanczos(self, seeds, lld):
+    def block_lanczos(self, seeds, lld, fatal_ok=False):
+        """recur_b.  A chain whose Krylov space is exhausted makes the reference call g_logger%fatal('Diagonalization error')
+        (recursion.f90:1942): DiagonalizationError here, unless fatal_ok (then that chain's coefficients are NaN from the failing level on)."""
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         n = len(seeds)
         a_b = np.zeros((18, 18, lld, n), np.complex128, order="F")
         b2_b = np.zeros_like(a_b)
         rc = lib().orc_block_lanczos(C.byref(self.P), n, seeds.ctypes.data_as(C.c_void_p), lld,
                                      a_b.ctypes.data_as(C.c_void_p), b2_b.ctypes.data_as(C.c_void_p))
-        assert rc == 0
+        if rc == 2 and not fatal_ok:
+            raise DiagonalizationError("Diagonalization error (recursion.f90:1942)", a_b, b2_b)
+        assert rc in (0, 2)
         return a_b, b2_b
 
-    def block_lanczos_seeded(self, seeds, coefs, lld):
+    def block_lanczos_seeded(self, seeds, coefs, lld, fatal_ok=False):
         """seeds (nchains, nseed) int, coefs (nchains, nseed) complex"""
         seeds = np.ascontiguousarray(seeds, dtype=np.int32)
         coefs = np.ascontiguousarray(coefs, dtype=np.complex128)
@@ -85,7 +97,9 @@ class Oracle:
         b2_b = np.zeros_like(a_b)
         rc = lib().orc_block_lanczos_seeded(C.byref(self.P), n, ns, seeds.ctypes.data_as(C.c_void_p), coefs.ctypes.data_as(C.c_void_p), lld,
                                             a_b.ctypes.data_as(C.c_void_p), b2_b.ctypes.data_as(C.c_void_p))
-        assert rc == 0
+        if rc == 2 and not fatal_ok:
+            raise DiagonalizationError("Diagonalization error (recursion.f90:1942)", a_b, b2_b)
+        assert rc in (0, 2)
         return a_b, b2_b
 
     def chebyshev_seeded(self, seeds, coefs, lld, a, b):

@@ -24,7 +24,7 @@ struct Eig18Shared {
 __device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ inline double2 cmulc(double2 a, double2 b) { /* a * conj(b) */ return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
-// In: sh.A = Hermitian matrix (column-major).  Out: sh.ev eigenvalues, sh.V eigenvectors. Returns sweeps used (<0: not converged).
+// In: sh.A = Hermitian matrix (column-major).  Out: sh.ev eigenvalues, sh.V eigenvectors. Returns sweeps used (-1: not converged, -2: non-finite input).
 __device__ inline int jacobi18(Eig18Shared& sh) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int e = tid; e < 324; e += nt) sh.V[e] = make_double2((e % 18) == (e / 18) ? 1.0 : 0.0, 0.0);
@@ -39,10 +39,15 @@ __device__ inline int jacobi18(Eig18Shared& sh) {
     double nrm = 0.0;
     for (int c = 0; c < 18; ++c) nrm += sh.red[c];
     __syncthreads();
-    if (!(nrm == nrm) || nrm > 1.0e300) {  // NaN / Inf in -> NaN out (the reference's zheev would propagate garbage, :1950)
+    if (!(nrm == nrm) || nrm > 1.0e300) {
+        // NaN / Inf in -> NaN out, reported as -2.  This is what a Krylov breakdown looks like one level later: sqrt of a
+        // rounding-negative (or 1 / an exactly zero) eigenvalue of B^2 puts NaN into B, B^-1 and every vector (recursion.f90:1950-1951),
+        // and the NEXT level's zheev gets a NaN matrix.  The compiled reference (MKL zheev) returns info /= 0 for it and crecal_b calls
+        // g_logger%fatal('Diagonalization error') (:1942) -- measured: oracle/make_fixtures.py fuzz_seed_case, the 8-atom cell at
+        // LL = 14; round 1-3 assumed a silent NaN here.  zsqr only prints the info (:2013) and goes on: its caller ignores -2.
         if (tid < 18) sh.ev[tid] = __builtin_nan("");
         __syncthreads();
-        return 0;
+        return -2;
     }
     int sweep = 0;
     for (; sweep < 40; ++sweep) {

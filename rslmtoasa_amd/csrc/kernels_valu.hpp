@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_zsqr(double2* mats, int* status) {
     for (int e = threadIdx.x; e < BLK; e += blockDim.x) sh.A[e] = M[e];
     __syncthreads();
     const int sw = jacobi18(sh);
-    if (sw < 0 && threadIdx.x == 0) atomicOr(status, 1);
+    if (sw == -1 && threadIdx.x == 0) atomicOr(status, 1);    // (non-finite input, -2: the reference's zsqr prints zheev's info and goes on, :2013)
     if (threadIdx.x < NB) sh.f1[threadIdx.x] = sqrt(sh.ev[threadIdx.x]);
     __syncthreads();
     matfun18(sh, sh.f1, M);

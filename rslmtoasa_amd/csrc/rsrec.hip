@@ -106,7 +106,6 @@ struct rsrec_handle {
     DevBuf d_la_extra;
     Spmm5Operator kubo_op[2], kubo_hbulk;   // v_a / v_b tables of the last rsrec_kubo_moments call
     Spmm5Operator orb_plain;                // h as ham_vec_matmul applies it when hoh is set (rsrec_orbital_moments, rsrec_apply_operator vel = 2)
-    void* rocblas_lib = nullptr; void* rocblas_handle = nullptr;
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
     DevBuf d_bsqrt, d_term, d_gim, d_ldos;   // LDOS stage on resident coefficients: sqrt(B^2), terminators, Im g0_jj, output images
@@ -173,7 +172,6 @@ struct rsrec_handle {
 
 namespace {
 
-int (*g_rocblas_destroy)(void*) = nullptr;     // set when rocBLAS is bound (Kubo path)
 
 int fail(rsrec_t* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -395,7 +393,6 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     h->s4_op.release();
     h->s5_op.release();
     h->kubo_op[0].release(); h->kubo_op[1].release(); h->kubo_hbulk.release(); h->orb_plain.release(); h->s5_la.release(); h->d_la_extra.release();
-    if (h->rocblas_handle && g_rocblas_destroy) g_rocblas_destroy(h->rocblas_handle);
     if (h->pin) (void)hipHostFree(h->pin);
     (void)hipStreamDestroy(h->stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -2228,36 +2225,6 @@ extern "C" int rsrec_chebyshev(rsrec_t* h, int nsites, const int32_t* seed_atoms
 // Stochastic Kubo double moments
 namespace {
 
-// rocBLAS is bound at the first Kubo call only (dlopen): the recursion / LDOS paths do not depend on it.
-struct RocblasApi {
-    int (*create)(void**) = nullptr;
-    int (*destroy)(void*) = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*zgemm)(void*, int, int, int, int, int, const void*, const void*, int, const void*, int, const void*, void*, int) = nullptr;
-};
-RocblasApi g_rocblas;
-
-int rocblas_ready(rsrec_t* h) {
-    if (!h->rocblas_lib) {
-        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return fail(h, RSREC_ERR_DEVICE, "rocBLAS not found (needed for the moment GEMM of the Kubo path): %s", dlerror());
-        g_rocblas.create = reinterpret_cast<int (*)(void**)>(dlsym(lib, "rocblas_create_handle"));
-        g_rocblas.destroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "rocblas_destroy_handle"));
-        g_rocblas_destroy = g_rocblas.destroy;
-        g_rocblas.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(lib, "rocblas_set_stream"));
-        g_rocblas.zgemm = reinterpret_cast<decltype(g_rocblas.zgemm)>(dlsym(lib, "rocblas_zgemm"));
-        if (!g_rocblas.create || !g_rocblas.set_stream || !g_rocblas.zgemm) return fail(h, RSREC_ERR_DEVICE, "rocBLAS symbols missing");
-        h->rocblas_lib = lib;
-    }
-    if (!h->rocblas_handle) {
-        if (g_rocblas.create(&h->rocblas_handle) != 0) return fail(h, RSREC_ERR_DEVICE, "rocblas_create_handle failed");
-        if (g_rocblas.set_stream(h->rocblas_handle, h->stream) != 0) return fail(h, RSREC_ERR_DEVICE, "rocblas_set_stream failed");
-    }
-    return RSREC_OK;
-}
-
 // Operator tables of a velocity-type operator (recursion.f90:587-784): which = 0 -> kubo_op[0] (v_a), 1 -> kubo_op[1] (v_b).
 //   set 0: V itself -- per-type blocks v_op(:,:,slot,type) for the bulk atoms; the reference has no velocity operator for the
 //          per-atom (impurity) region yet (":591 NOT YET IMPLEMENTED"): those rows of V psi are zero, as there.
@@ -2373,15 +2340,15 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     HIPCK(h, hipSetDevice(h->device));
     reset_timing(h);
     if (nvec == 0) return RSREC_OK;
-    rc = rocblas_ready(h); if (rc) return rc;
     rc = build_kubo_operator(h, 0, v_a, vo_a); if (rc) return rc;
     rc = build_kubo_operator(h, 1, v_b, vo_b); if (rc) return rc;
     if (h->hoh && h->nmax > 0) { rc = build_kubo_hbulk(h); if (rc) return rc; }
     const int kk = h->kk;
     const size_t velems = (size_t)(kk + 1) * BLD, nd = (size_t)kk * BLD;
-    const size_t ld = (size_t)kk * NB;                       // rows of the moment matrices: (atom, orbital row)
-    const int nchunk = std::min(cond_ll, 64);                // right vectors per GEMM
-    // device memory: 11 work vectors, a chunk of the left matrix (lchunk vectors), one chunk of right vectors, one chunk of moments.
+    const int nchunk = std::min(cond_ll, 64);                // right vectors per contraction
+    // The moment contraction L^H R is k_kubo_gram on the vectors where they lie (CI layout = dense row-major (18 kk) x 18 matrices side by
+    // side): the slots of Lm / Rm ARE the left / right vectors, written there by the SpMMs themselves.
+    // device memory: 11 work vectors, `lchunk` left vectors, one chunk of right vectors, the slices' partial blocks, one vector's moments.
     // The left matrix is held in chunks of `lchunk` vectors (all of them if they fit: cond_ll x kk x 5184 B is 21 GB for cond_ll = 500
     // on 8 000 atoms, 252 GB on 10^5): each chunk continues the left recurrence where the previous one stopped and is contracted
     // with ALL right vectors, so the right recurrence (2 of the 3 SpMMs per moment order) is repeated once per chunk.
@@ -2390,25 +2357,37 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     size_t reusable = 0;
     for (int v = 0; v < 6; ++v) reusable += h->d_vec[v].bytes;
     const double budget = 0.9 * (double)(free_b + reusable);
-    auto need_for = [&](int lc) { return 11.0 * velems * 8 + ((double)lc + nchunk) * ld * NB * 16 + (double)lc * NB * nchunk * NB * 16; };
+    const int ksteps_total = (int)((NB * (size_t)kk + 3) / 4);            // k-steps of 4 rows (the last one may end inside the zero block)
+    const int nbn_max = (nchunk * NB + KG_BLK - 1) / KG_BLK;
+    // slices of the row index per contraction: enough wave tasks for a few rounds of the device, at least 64 k-steps per task
+    auto ksplit_for = [&](int lc) {
+        const long blocks = (long)((lc * NB + KG_BLK - 1) / KG_BLK) * nbn_max;
+        long ksp = (4L * 8 * h->n_cu + blocks - 1) / std::max(1L, blocks);
+        ksp = std::min<long>({ksp, 64, std::max(1, ksteps_total / 64)});
+        return (int)std::max<long>(8, (ksp + 7) / 8 * 8);
+    };
+    auto part_bytes = [&](int lc) { return (double)ksplit_for(lc) * ((lc * NB + KG_BLK - 1) / KG_BLK) * KG_BLK * (double)nbn_max * KG_BLK * 16.0; };
+    auto need_for = [&](int lc) { return (11.0 + lc + nchunk) * velems * 8 + part_bytes(lc) + (double)cond_ll * cond_ll * BLK * 16.0; };
     int lchunk = cond_ll;
     if (h->opt_kubo_lchunk > 0) lchunk = (int)std::min<long>(cond_ll, h->opt_kubo_lchunk);
     while (lchunk > 1 && need_for(lchunk) > budget) lchunk = (lchunk + 1) / 2;
     if (need_for(lchunk) > budget)
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for one left vector at a time on %d atoms, %.1f GB free", need_for(1) * 1e-9, kk, free_b * 1e-9);
     for (int v = 0; v < 6; ++v) h->d_vec[v].release();
-    DevBuf work, Lm, Rm, Mu;
-    auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Mu.release(); };
-    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)lchunk * ld * NB * 16) != hipSuccess ||
-        Rm.reserve((size_t)nchunk * ld * NB * 16) != hipSuccess || Mu.reserve((size_t)lchunk * NB * nchunk * NB * 16) != hipSuccess) {
+    DevBuf work, Lm, Rm, Part, Mu;
+    auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Part.release(); Mu.release(); };
+    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)lchunk * velems * 8) != hipSuccess || Rm.reserve((size_t)nchunk * velems * 8) != hipSuccess ||
+        Part.reserve((size_t)part_bytes(lchunk)) != hipSuccess || Mu.reserve((size_t)cond_ll * cond_ll * BLK * 16) != hipSuccess) {
         cleanup();
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: out of device memory");
     }
+    HIPCK(h, hipMemsetAsync(Lm.p, 0, (size_t)lchunk * velems * 8, h->stream));    // (block kk of every slot stays the zero block)
+    HIPCK(h, hipMemsetAsync(Rm.p, 0, (size_t)nchunk * velems * 8, h->stream));
     HIPCK(h, hipMemsetAsync(work.p, 0, 11 * velems * 8, h->stream));            // block kk of every vector stays the zero block
     double* V[11];
     for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * velems;
-    double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3], *right = V[5];
-    double *l0 = V[4], *l1 = V[9], *l2 = V[10];                                 // state of the left recurrence (survives from chunk to chunk)
+    double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3];
+    double *l0 = V[4], *l1 = V[9];                                              // T_{m0-2} r, T_{m0-1} r: the left recurrence across a chunk border
     HIPCK(h, h->d_seed.reserve((size_t)nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)nseed * sizeof(double2)));
     // region list: all atoms (every launch of this path runs over the whole lattice)
@@ -2429,9 +2408,10 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     K.spmm_ev = &spmm_ev;
     std::vector<std::tuple<const Spmm5Operator*, int, double>> req_tab;
     K.req = &req_tab;
-    std::vector<double> mu_chunk((size_t)lchunk * NB * nchunk * NB * 2);
     hipEvent_t e_begin = next_event(h);
     int n_left_chunks = 0;
+    auto Lslot = [&](int q) { return Lm.as<double>() + (size_t)q * velems; };
+    auto Rslot = [&](int q) { return Rm.as<double>() + (size_t)q * velems; };
     for (int iv = 0; iv < nvec; ++iv) {
         // r_i: psiref(l,l,seed(k)) = coef(k); seed atom 0 = unused entry
         std::vector<int> s0; std::vector<double> c0;
@@ -2445,23 +2425,26 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         XFER(xfer_h2d(h, h->d_seedcoef.p, c0.data(), c0.size() * 8));
         HIPCK(h, hipMemsetAsync(psiref, 0, nd * 8, h->stream));
         k_seed<LayoutCI><<<1, 64, 0, h->stream>>>(psiref, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), (int)s0.size());
-        double *x0 = l0, *x1 = l1, *x2 = l2;
-        HIPCK(h, hipMemcpyAsync(x1, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
         for (int m0 = 0; m0 < cond_ll; m0 += lchunk) {
             const int ml = std::min(lchunk, cond_ll - m0), m_rows = ml * NB;
             ++n_left_chunks;
-            // left vectors  T_{m-1}(H~) r,  m = m0 .. m0 + ml - 1  ->  columns of L (recursion.f90:1120-1142)
+            // left vectors  T_{m-1}(H~) r,  m = m0 .. m0 + ml - 1 (recursion.f90:1120-1142), each written by its SpMM into its slot of Lm;
+            // the recurrence reads the two slots before it -- across a chunk border the copies l0 = T_{m0-2} r, l1 = T_{m0-1} r
             for (int m = m0; m < m0 + ml; ++m) {
-                if (m == 1) {
-                    std::swap(x0, x1);                                        // w0 = w1
-                    kubo_apply_h(K, x0, x1, cheb_epilogue(true, x0, nullptr, a, b));
-                } else if (m > 1) {
-                    kubo_apply_h(K, x1, x2, cheb_epilogue(false, x1, x0, a, b));
-                    double* o = x0; x0 = x1; x1 = x2; x2 = o;                 // w0 = w1, w1 = w2
-                }
-                k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(x1), Lm.as<double2>(), ld, (m - m0) * NB);
+                double* out = Lslot(m - m0);
+                const double* prev1 = m - 1 >= m0 ? Lslot(m - 1 - m0) : l1;
+                const double* prev2 = m - 2 >= m0 ? Lslot(m - 2 - m0) : l0;
+                if (m == 0) HIPCK(h, hipMemcpyAsync(out, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
+                else if (m == 1) kubo_apply_h(K, prev1, out, cheb_epilogue(true, prev1, nullptr, a, b));
+                else kubo_apply_h(K, prev1, out, cheb_epilogue(false, prev1, prev2, a, b));
             }
-            // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), contracted with the left vectors of this chunk, 64 at a time
+            if (m0 + ml < cond_ll) {                                          // state for the next chunk (its slots are about to be reused)
+                if (ml >= 2) HIPCK(h, hipMemcpyAsync(l0, Lslot(ml - 2), nd * 8, hipMemcpyDeviceToDevice, h->stream));
+                else HIPCK(h, hipMemcpyAsync(l0, l1, nd * 8, hipMemcpyDeviceToDevice, h->stream));
+                HIPCK(h, hipMemcpyAsync(l1, Lslot(ml - 1), nd * 8, hipMemcpyDeviceToDevice, h->stream));
+            }
+            // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), written into the slots of Rm and contracted with the left vectors of
+            // this chunk, 64 at a time
             double *y0 = w0, *y1 = w1, *y2 = w2;
             kubo_apply_v(K, h->kubo_op[1], psiref, y1);                       // v1 = v0 = v_b r
             for (int n = 0; n < cond_ll; ++n) {
@@ -2472,41 +2455,33 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
                     kubo_apply_h(K, y1, y2, cheb_epilogue(false, y1, y0, a, b));
                     double* o = y0; y0 = y1; y1 = y2; y2 = o;
                 }
-                kubo_apply_v(K, h->kubo_op[0], y1, right);
                 const int nl = n % nchunk;
-                k_vec_to_cols<<<std::min(kk, 2048), 384, 0, h->stream>>>(kk, reinterpret_cast<const double2*>(right), Rm.as<double2>(), ld, nl * NB);
+                kubo_apply_v(K, h->kubo_op[0], y1, Rslot(nl));
                 if (nl == nchunk - 1 || n == cond_ll - 1) {
-                    const int ncols = (nl + 1) * NB;
-                    const double one[2] = {1.0, 0.0}, zero[2] = {0.0, 0.0};
+                    const int ncols = (nl + 1) * NB, n0 = n - nl;
+                    const int nbm = (m_rows + KG_BLK - 1) / KG_BLK, nbn = (ncols + KG_BLK - 1) / KG_BLK;
+                    long ksp = (4L * 8 * h->n_cu + (long)nbm * nbn - 1) / ((long)nbm * nbn);
+                    ksp = std::min<long>({ksp, (long)ksplit_for(lchunk), std::max(1, ksteps_total / 64)});
+                    const int ksplit = (int)std::max<long>(8, (ksp + 7) / 8 * 8);
                     HIPCK(h, hipGetLastError());
                     hipEvent_t g0 = next_event(h);
-                    HIPCK(h, hipMemsetAsync(Mu.p, 0, (size_t)m_rows * ncols * 16, h->stream));     // (beta = 0 below; the buffer is fresh device memory)
-                    // Mu[(m,c), (n,c')] = sum_{k,r} conj(L[(k,r),(m,c)]) R[(k,r),(n,c')]    (zgemm 'C','N'; rocblas_operation codes 113 / 111)
-                    if (g_rocblas.zgemm(h->rocblas_handle, 113, 111, m_rows, ncols, (int)ld, one, Lm.p, (int)ld, Rm.p, (int)ld, zero, Mu.p, m_rows) != 0) {
-                        cleanup();
-                        return fail(h, RSREC_ERR_DEVICE, "rocblas_zgemm failed");
-                    }
+                    // C[(m,c)][(n,c')] = sum_{k,r} conj(L_m[(k,r)][c]) R_n[(k,r)][c']: 48 x 48 blocks x `ksplit` slices of (k,r), one wave each
+                    const unsigned wgs = 8u * (unsigned)(((long)nbm * nbn * (ksplit / 8) + 3) / 4);
+                    k_kubo_gram<<<wgs, 256, 0, h->stream>>>(Lm.as<double>(), velems, m_rows, Rm.as<double>(), velems, ncols, ksteps_total, ksplit, Part.as<double2>(), nbm, nbn);
+                    k_kubo_gram_reduce<<<std::min(4096, (m_rows * ncols + 255) / 256), 256, 0, h->stream>>>(Part.as<double2>(), ksplit, nbm, nbn, m_rows, ncols, Mu.as<double2>(), cond_ll, m0, n0);
                     gemm_ev.emplace_back(g0, next_event(h));
-                    XFER(xfer_d2h(h, mu_chunk.data(), Mu.p, (size_t)m_rows * ncols * 16));
-                    const int n0 = n - nl;
-                    for (int q = 0; q <= nl; ++q)
-                        for (int cp = 0; cp < NB; ++cp)
-                            for (int m = 0; m < ml; ++m)
-                                for (int c = 0; c < NB; ++c) {
-                                    const size_t src = 2 * ((size_t)(m * NB + c) + (size_t)m_rows * (q * NB + cp));
-                                    const size_t dst = 2 * ((size_t)c + NB * ((size_t)cp + NB * ((size_t)(n0 + q) + cond_ll * ((size_t)(m0 + m) + (size_t)cond_ll * iv))));
-                                    mu_nm[dst] = mu_chunk[src]; mu_nm[dst + 1] = mu_chunk[src + 1];
-                                }
                 }
             }
         }
+        HIPCK(h, hipGetLastError());
+        XFER(xfer_d2h(h, mu_nm + 2 * (size_t)BLK * cond_ll * cond_ll * iv, Mu.p, (size_t)cond_ll * cond_ll * BLK * 16));
     }
     hipEvent_t e_end = next_event(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipGetLastError());
     h->t_total_ms = ev_ms(e_begin, e_end);
     for (auto& pr : spmm_ev) h->t_hop_ms += ev_ms(pr.first, pr.second);          // the SpMM kernels (H and velocity products)
-    for (auto& pr : gemm_ev) h->t_rest_ms += ev_ms(pr.first, pr.second);         // "rest_ms" here: the moment GEMMs (rocBLAS zgemm)
+    for (auto& pr : gemm_ev) h->t_rest_ms += ev_ms(pr.first, pr.second);         // "rest_ms" here: the moment contractions (k_kubo_gram + its reduction)
     h->n_hop_launch = (double)spmm_ev.size();
     h->n_kubo_left_chunks = n_left_chunks;
     // work in the reference's terms: every product is over the whole lattice -- one block multiply per (atom, present slot)

@@ -138,3 +138,31 @@ def supercell_problem(dims, hoh=False):
     if hoh:
         p.update(eeo=st["eeo"], enim=st["enim"])
     return p
+
+
+def orbital_unit50_energy_resolved(mu_sum, kk, a, b, ene):
+    """Column 3 of the file chebyshev_orbital_mod writes to unit 50 (recursion.f90:3007-3046) from the moments summed over all seed
+    atoms, `mu_sum` (18,18,lld): 1/kk, Jackson kernel (math.f90:1641-1655), factor 2 from the second moment on, the energy sum with
+    aimag(-i exp(-i (n-1) acos w)) = -cos((n-1) acos w), the trace, -1/pi.  A LINEAR map of Re tr(mu_n): it is how the reference's file pins
+    the moments themselves (7 significant digits: format 3es16.6).  Column 2 is the Simpson integral of column 3 (simpson_f, which reads
+    one element past its arrays -- oracle/make_scf_fixtures.py) and is not restated."""
+    lld = mu_sum.shape[2]
+    n = np.arange(lld, dtype=np.float64)
+    theta = np.pi * n / (lld + 1.0)
+    kern = ((lld - n + 1.0) * np.cos(theta) + np.sin(theta) / np.tan(np.pi / (lld + 1.0))) / (lld + 1.0)
+    kern[1:] *= 2.0
+    tr = np.trace(mu_sum, axis1=0, axis2=1).real / float(kk) * kern                    # rtrace of every moment
+    w = (np.asarray(ene) - b) / a
+    lzi = -(np.cos(np.outer(np.arccos(w), n)) @ tr) / np.sqrt(a * a - (np.asarray(ene) - b) ** 2)
+    return -lzi / np.pi
+
+
+def random_vec_coefficients(rng):
+    """The vectors cond_calctype = 'random_vec' builds from its random numbers `rng` (kk, nvec) (recursion.f90:1130-1138):
+    psiref(m, m, k) = exp(2 pi i rng_k), then the whole vector divided by sqrt(real(kk)) -- `real()` is default REAL(4) there, so the
+    norm is the single-precision square root, widened.  Returns (seeds (nvec, kk) int32, coefs (nvec, kk) complex128)."""
+    kk, nvec = rng.shape
+    norm = float(np.sqrt(np.float32(kk)))
+    coefs = np.ascontiguousarray((np.exp(2.0 * np.pi * 1j * rng) / norm).T)
+    seeds = np.tile(np.arange(1, kk + 1, dtype=np.int32), (nvec, 1))
+    return seeds, coefs

@@ -53,6 +53,23 @@ def test_kubo_moments_match_reference(name, oracle_lib):
     rec.close()
 
 
+def test_kubo_random_vec_branch_matches_reference():
+    """cond_calctype = 'random_vec' against the COMPILED REFERENCE (tests/golden/fccPt_kubo_random.npz: its moments and the random
+    numbers it drew, round 4): rsrec_kubo_moments on the reference's own vectors, 1e-10."""
+    from helpers import random_vec_coefficients
+    z = load_golden("fccPt_kubo_random")
+    rec, p = make_rec(z)
+    seeds, coefs = random_vec_coefficients(z["rng"])
+    import rslmtoasa_amd.recursion as R
+    orig = scaled(rec, z)
+    try:
+        mu = rec.compute_moments_stochastic(z["v_a"], z["v_b"], int(z["cond_ll"]), seeds=seeds, coefs=coefs)
+    finally:
+        R.chebyshev_scaling = orig
+    assert mu.shape == z["mu_nm"].shape and vec_err(mu, z["mu_nm"]) < RTOL
+    rec.close()
+
+
 @pytest.mark.parametrize("name", KUBO_CASES)
 def test_kubo_random_vectors_match_oracle(name, oracle_lib):
     """cond_calctype = 'random_vec' (recursion.f90:1103-1114): every atom carries a random phase / sqrt(kk); two vectors."""

@@ -12,14 +12,14 @@ import shutil
 import numpy as np
 import pytest
 
-from helpers import RTOL, load_golden, require_built
+from helpers import RTOL, load_golden, orbital_unit50_energy_resolved, require_built
 from oracle.make_fixtures import ORBITAL_CASES, patch_namelist
 from rslmtoasa_amd._proc import run_with_unlimited_stack
 from rslmtoasa_amd.recursion import Control, Energy, Hamiltonian, Lattice, Recursion
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["fccPt_orbital", "fccPt_orbital_hoh"]
+CASES = ["fccPt_orbital", "fccPt_orbital_hoh", "bccFe_orbital"]      # the last: ferromagnetic bcc Fe with spin-orbit coupling (round 4), a non-zero orbital moment
 
 
 def make_rec(z, lld):
@@ -53,6 +53,13 @@ def test_orbital_moments_match_oracle(name, oracle_lib):
     assert np.all(err <= RTOL * np.maximum(scale, 1e-3 * scale.max())), float((err / np.maximum(scale, 1e-3 * scale.max())).max())
     assert np.abs(mu * kk - mu_o).max() <= RTOL * np.abs(ms_o).max()         # the sum over all seeds (cancels to ~0 in parts: absolute bar)
     assert np.abs(mu_sub - ms_o[:, :, :, sub - 1].sum(axis=3)).max() <= RTOL * np.abs(ms_o).max()
+    if name == "bccFe_orbital":
+        # magnetic case: the GPU's own moments against the REFERENCE's unit-50 file (energy-resolved column: a linear map of Re tr(mu_n),
+        # 7 printed digits) -- the moments themselves are pinned here, not only the left vectors
+        f50 = z["fort50"]
+        col3 = orbital_unit50_energy_resolved(mu * kk, kk, a, b, z["ene"])
+        assert np.abs(f50[:, 2]).max() > 1e-4
+        assert np.all(np.abs(col3 - f50[:, 2]) <= 5.1e-7 * np.abs(f50[:, 2]) + 1e-9 * np.abs(f50[:, 2]).max()), float(np.abs(col3 - f50[:, 2]).max())
 
 
 def test_fortran_override_reproduces_the_reference_file(tmp_path):
@@ -73,3 +80,30 @@ def test_fortran_override_reproduces_the_reference_file(tmp_path):
     assert rows.shape == ref.shape
     assert np.abs(rows[:, 0] - ref[:, 0]).max() <= 1e-6 * np.abs(ref[:, 0]).max()
     assert np.abs(ref[:, 2]).max() < 1e-9 and np.abs(rows[:, 2]).max() < 1e-9
+
+
+def test_zero_edit_program_reproduces_the_reference_file_on_a_magnetic_case(tmp_path):
+    """The reference's OWN main program (rslmto_dropin.x: unmodified sources, GPU types behind the module names) with
+    post_processing = 'orbital_modern' (calculation.f90:208, :1158-1269) on ferromagnetic bcc Fe with spin-orbit coupling: unit 50 --
+    E - E_F, the integrated and the energy-resolved orbital moment -- against the compiled reference's file of the same run
+    (tests/golden/bccFe_orbital.npz), all three columns to the printed digits.  recursion%chebyshev_orbital_mod is the device-resident
+    loop (rsrec_orbital_moments) behind `type(recursion)`."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "rslmto_dropin.x")
+    require_built(exe)
+    z = load_golden("bccFe_orbital")
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "scf", "inputs", "bulk_bccFe"), work)
+    inp = work / "input.nml"
+    # (pre_processing = 'none': the fixture's run -- oracle/dump_kubo.f90 -- goes straight to the post-processing branch; the case file's
+    # 'bravais' would run an SCF iteration first and move the Fermi level the output is referred to)
+    patch = dict(ORBITAL_CASES["bccFe_orbital"][1], calculation={"pre_processing": "'none'", "post_processing": "'orbital_modern'"})
+    inp.write_text(patch_namelist(inp.read_text(), patch))
+    r = run_with_unlimited_stack([exe], cwd=work, env={"OMP_NUM_THREADS": "8", "RSREC_REPORT": "1"}, timeout=900, scrub=False)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and "fatal" not in log.lower() and "chebyshev-orbital-gpu" in log and "rsrec report: library_calls=" in log, log[-3000:]
+    rows = np.array([[float(v) for v in l.split()] for l in (work / "fort.50").read_text().splitlines() if l.strip()])
+    ref = z["fort50"]
+    assert rows.shape == ref.shape and np.abs(ref[:, 2]).max() > 1e-4
+    for col in range(3):
+        # 7 printed digits; a last-digit flip of either file is one unit of its 7th digit
+        assert np.all(np.abs(rows[:, col] - ref[:, col]) <= 2.1e-6 * np.abs(ref[:, col]) + 1e-9 * np.abs(ref[:, col]).max()), (col, float(np.abs(rows[:, col] - ref[:, col]).max()))

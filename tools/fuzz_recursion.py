@@ -41,11 +41,31 @@ if __name__ == "__main__":
             o = oracle.Oracle(p)
             errs = []
             noct = 0
-            for rep in range(2):                                  # twice: the second call reuses cached regions / a captured graph
-                rec.recur_b()
-                noct += int(rec.timing()["octet_launches"])
+            # A chain whose Krylov space runs out ends the reference's run ('Diagonalization error', recursion.f90:1942; the oracle
+            # raises, the engine returns RSREC_ERR_EIG).  Whether a vanishing eigenvalue of B^2 comes out as -1e-17 (fatal) or +1e-17
+            # (garbage, but finite) is rounding: a case where only one of the two ends is reported as EDGE, not judged.
+            try:
                 a_o, b_o = o.block_lanczos(irec, lld)
-                errs += [rel_err(rec.a_b, a_o), rel_err(rec.b2_b, b_o)]
+                oracle_fatal = False
+            except oracle.DiagonalizationError:
+                oracle_fatal = True
+            engine_fatal = False
+            for rep in range(2):                                  # twice: the second call reuses cached regions / a captured graph
+                try:
+                    rec.recur_b()
+                except Exception as e:
+                    if "Diagonalization error" not in str(e):
+                        raise
+                    engine_fatal = True
+                    break
+                noct += int(rec.timing()["octet_launches"])
+                if not oracle_fatal:
+                    errs += [rel_err(rec.a_b, a_o), rel_err(rec.b2_b, b_o)]
+            if oracle_fatal or engine_fatal:
+                rec.close()
+                print("%s %s  (oracle fatal=%s, engine fatal=%s)" % ("ok  " if oracle_fatal == engine_fatal else "EDGE", tag, oracle_fatal, engine_fatal), flush=True)
+                ncase += 1; seed += 1
+                continue
             rec.chebyshev_recur()
             mu_o, div = o.chebyshev(irec, lld, *chebyshev_scaling(-60.0, 60.0))
             errs.append(rel_err(rec.mu_n, mu_o))
@@ -64,8 +84,14 @@ if __name__ == "__main__":
                     rp.set_option(k, v)
                 rp.update_hamiltonian()
                 slots, sa, sc = rp._pair_seeds(pairs, skip_diagonal_repeats=True)
-                rp.recur_b_ij()
-                a_p, b_p = o.block_lanczos_seeded(sa, sc, lld)
+                a_p, b_p = o.block_lanczos_seeded(sa, sc, lld, fatal_ok=True)
+                try:
+                    rp.recur_b_ij()
+                    pair_fatal = False
+                except Exception as e:
+                    if "Diagonalization error" not in str(e):
+                        raise
+                    pair_fatal = True
                 cond_p = 1.0                                       # (pair chains on a random directed graph often die out: see the ILL rule below)
                 for l in range(lld):
                     for c in range(b_p.shape[3]):
@@ -74,7 +100,9 @@ if __name__ == "__main__":
                             cond_p = max(cond_p, ev.max() / max(abs(ev.min()), 1e-300))
                         except Exception:
                             cond_p = np.inf
-                if cond_p < 1e3:
+                if pair_fatal or not np.isfinite(a_p).all():
+                    extra = " +pairs(%s)" % ("both end in the fatal error" if pair_fatal and not np.isfinite(a_p).all() else "EDGE: one of engine / oracle ends in the fatal error")
+                elif cond_p < 1e3:
                     errs += [rel_err(rp.a_b[:, :, :, slots], a_p), rel_err(rp.b2_b[:, :, :, slots], b_p)]
                     extra = " +pairs"
                 else:
@@ -105,7 +133,9 @@ if __name__ == "__main__":
                             cond = max(cond, ev.max() / max(abs(ev.min()), 1e-300))
                         except Exception:
                             cond = np.inf
-                if max(errs) < 1e-16 * cond ** 2:
+                # (an unknown condition number -- eigvalsh failed, NaN -- excuses nothing, and no condition number excuses more than 1e-6;
+                # tests/test_gpu_breakdown.py holds the round-3 ILL seeds to the COMPILED REFERENCE's own sensitivity instead)
+                if np.isfinite(cond) and max(errs) < min(1e-16 * cond ** 2, 1e-6):
                     verdict, ok = "ILL ", True
                     tag += " cond(B^2)=%.1e" % cond
             print("%s %s  worst %.1e" % (verdict, tag, max(errs)), flush=True)
