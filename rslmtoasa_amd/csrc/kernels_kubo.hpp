@@ -64,17 +64,12 @@ __global__ __launch_bounds__(256, 2) void k_kubo_gram(const double* __restrict__
 #pragma unroll
         for (int u = 0; u < KG_T; ++u) { cre[q][u] = (double4_t){0, 0, 0, 0}; cim[q][u] = (double4_t){0, 0, 0, 0}; }
     typedef double kg_d2 __attribute__((ext_vector_type(2)));
-    kg_d2 a[KG_T], b[KG_T], an[KG_T], bn_[KG_T];
-    if (s0 < s1) {
+    kg_d2 a0[KG_T], b0[KG_T], a1[KG_T], b1[KG_T];          // two operand sets, used alternately (no register copies in the loop)
+    auto fetch = [&](kg_d2 (&a)[KG_T], kg_d2 (&b)[KG_T]) {
 #pragma unroll
-        for (int q = 0; q < KG_T; ++q) { a[q] = *reinterpret_cast<const kg_d2*>(pa[q]); b[q] = *reinterpret_cast<const kg_d2*>(pb[q]); }
-    }
-#pragma unroll 1
-    for (int s = s0; s < s1; ++s) {
-        if (s + 1 < s1) {
-#pragma unroll
-            for (int q = 0; q < KG_T; ++q) { pa[q] += 144; pb[q] += 144; an[q] = *reinterpret_cast<const kg_d2*>(pa[q]); bn_[q] = *reinterpret_cast<const kg_d2*>(pb[q]); }
-        }
+        for (int q = 0; q < KG_T; ++q) { a[q] = *reinterpret_cast<const kg_d2*>(pa[q]); b[q] = *reinterpret_cast<const kg_d2*>(pb[q]); pa[q] += 144; pb[q] += 144; }
+    };
+    auto mac = [&](const kg_d2 (&a)[KG_T], const kg_d2 (&b)[KG_T]) {
 #pragma unroll
         for (int q = 0; q < KG_T; ++q) {
             const double ar = a[q][0], ai = a[q][1], nai = -ai;
@@ -86,9 +81,17 @@ __global__ __launch_bounds__(256, 2) void k_kubo_gram(const double* __restrict__
                 cim[q][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[u][0], cim[q][u], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int q = 0; q < KG_T; ++q) { a[q] = an[q]; b[q] = bn_[q]; }
+    };
+    int s = s0;
+    if (s < s1) fetch(a0, b0);
+#pragma unroll 1
+    for (; s + 2 <= s1; s += 2) {
+        fetch(a1, b1);
+        mac(a0, b0);
+        if (s + 2 < s1) fetch(a0, b0);
+        mac(a1, b1);
     }
+    if (s < s1) mac(a0, b0);
     // D register rr of lane (l15, l4): row l4 + 4 rr, column l15 of the tile.  Partial blocks: part[ks][i][j], row-major over the PADDED
     // block grid (nbm x 48 rows, nbn x 48 columns): sixteen consecutive complex numbers per lane row
     const size_t ldp = (size_t)nbn * KG_BLK;
@@ -104,11 +107,14 @@ __global__ __launch_bounds__(256, 2) void k_kubo_gram(const double* __restrict__
             }
 }
 
+// (Measured and not kept, round 4: the same contraction on v_mfma_f64_4x4x4_4b -- A operand = 4 rows replicated over the instruction's
+// four blocks, 32 x 48 of C per wave, 8 A + 3 B loads per 96 instructions.  The shape sustains 70-75 TFLOP/s in isolation
+// (profiles/ubench_f64_r01.txt) but the kernel reached 50.0 / 55.7 TFLOP/s at cond_ll = 50 / 500 against 59.1 / 64.1 for this one.)
 // sum of the slices' partial blocks in slice order -> mu_nm(c, c', n0 + n, m0 + m) in the reference's index order
 // (mu_nm_stochastic(18,18,cond_ll,cond_ll,vec), recursion.f90:1204-1228); one thread per (i, j)
-__global__ __launch_bounds__(256) void k_kubo_gram_reduce(const double2* __restrict__ part, int ksplit, int nbm, int nbn, int mrows, int ncols,
+__global__ __launch_bounds__(256) void k_kubo_gram_reduce(const double2* __restrict__ part, int ksplit, int prow /*padded rows of a slice*/, int pcol, int mrows, int ncols,
                                                          double2* __restrict__ mu /*this vector's (18,18,cond_ll,cond_ll)*/, int cond_ll, int m0, int n0) {
-    const size_t ldp = (size_t)nbn * KG_BLK, slice = (size_t)nbm * KG_BLK * ldp;
+    const size_t ldp = (size_t)pcol, slice = (size_t)prow * ldp;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)mrows * ncols; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / ncols), j = (int)(e - (size_t)i * ncols);
         double sr = 0.0, si = 0.0;

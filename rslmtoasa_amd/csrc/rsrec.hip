@@ -2362,7 +2362,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     // slices of the row index per contraction: enough wave tasks for a few rounds of the device, at least 64 k-steps per task
     auto ksplit_for = [&](int lc) {
         const long blocks = (long)((lc * NB + KG_BLK - 1) / KG_BLK) * nbn_max;
-        long ksp = (4L * 8 * h->n_cu + blocks - 1) / std::max(1L, blocks);
+        long ksp = (12L * 8 * h->n_cu + blocks - 1) / std::max(1L, blocks);          // up to a dozen rounds of the device's wave slots
         ksp = std::min<long>({ksp, 64, std::max(1, ksteps_total / 64)});
         return (int)std::max<long>(8, (ksp + 7) / 8 * 8);
     };
@@ -2433,7 +2433,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
             for (int m = m0; m < m0 + ml; ++m) {
                 double* out = Lslot(m - m0);
                 const double* prev1 = m - 1 >= m0 ? Lslot(m - 1 - m0) : l1;
-                const double* prev2 = m - 2 >= m0 ? Lslot(m - 2 - m0) : l0;
+                const double* prev2 = m - 2 >= m0 ? Lslot(m - 2 - m0) : (m - 2 == m0 - 1 ? l1 : l0);
                 if (m == 0) HIPCK(h, hipMemcpyAsync(out, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
                 else if (m == 1) kubo_apply_h(K, prev1, out, cheb_epilogue(true, prev1, nullptr, a, b));
                 else kubo_apply_h(K, prev1, out, cheb_epilogue(false, prev1, prev2, a, b));
@@ -2459,16 +2459,26 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
                 kubo_apply_v(K, h->kubo_op[0], y1, Rslot(nl));
                 if (nl == nchunk - 1 || n == cond_ll - 1) {
                     const int ncols = (nl + 1) * NB, n0 = n - nl;
-                    const int nbm = (m_rows + KG_BLK - 1) / KG_BLK, nbn = (ncols + KG_BLK - 1) / KG_BLK;
-                    long ksp = (4L * 8 * h->n_cu + (long)nbm * nbn - 1) / ((long)nbm * nbn);
-                    ksp = std::min<long>({ksp, (long)ksplit_for(lchunk), std::max(1, ksteps_total / 64)});
-                    const int ksplit = (int)std::max<long>(8, (ksp + 7) / 8 * 8);
+                    // C[(m,c)][(n,c')] = sum_{k,r} conj(L_m[(k,r)][c]) R_n[(k,r)][c']: blocks of C x `ksplit` slices of (k,r), one wave each.
+                    const int bmr = KG_BLK, bnc = KG_BLK;
+                    const int nbm = (m_rows + bmr - 1) / bmr, nbn = (ncols + bnc - 1) / bnc;
+                    // slices: the multiple of 8 (<= what the partial buffer was sized for, >= 64 k-steps per task) that fills whole rounds of
+                    // the device's wave slots best -- 361 blocks x 24 slices are 4.2 rounds of 2 048 slots (85 % of the last round idle), x 32 are 5.6
+                    int ksplit = 8;
+                    {
+                        const long slots = 8L * h->n_cu, cap = std::min<long>(ksplit_for(lchunk), std::max(8, ksteps_total / 64 / 8 * 8));
+                        double best = 0.0;
+                        for (long c = 8; c <= cap; c += 8) {
+                            const long tasks = (long)nbm * nbn * c, rounds = (tasks + slots - 1) / slots;
+                            const double eff = (double)tasks / (double)(rounds * slots) * (rounds >= 3 ? 1.0 : 0.9);   // (few rounds: the tail of the slowest wave shows)
+                            if (eff > best + 1e-9) { best = eff; ksplit = (int)c; }
+                        }
+                    }
                     HIPCK(h, hipGetLastError());
                     hipEvent_t g0 = next_event(h);
-                    // C[(m,c)][(n,c')] = sum_{k,r} conj(L_m[(k,r)][c]) R_n[(k,r)][c']: 48 x 48 blocks x `ksplit` slices of (k,r), one wave each
                     const unsigned wgs = 8u * (unsigned)(((long)nbm * nbn * (ksplit / 8) + 3) / 4);
                     k_kubo_gram<<<wgs, 256, 0, h->stream>>>(Lm.as<double>(), velems, m_rows, Rm.as<double>(), velems, ncols, ksteps_total, ksplit, Part.as<double2>(), nbm, nbn);
-                    k_kubo_gram_reduce<<<std::min(4096, (m_rows * ncols + 255) / 256), 256, 0, h->stream>>>(Part.as<double2>(), ksplit, nbm, nbn, m_rows, ncols, Mu.as<double2>(), cond_ll, m0, n0);
+                    k_kubo_gram_reduce<<<std::min(4096, (m_rows * ncols + 255) / 256), 256, 0, h->stream>>>(Part.as<double2>(), ksplit, nbm * bmr, nbn * bnc, m_rows, ncols, Mu.as<double2>(), cond_ll, m0, n0);
                     gemm_ev.emplace_back(g0, next_event(h));
                 }
             }
