@@ -84,14 +84,18 @@ __device__ __forceinline__ void gauss_jordan_step(double2 (&q)[2][3], GreenLds& 
     double2 cx = make_double2(0.0, 0.0);
     double v = -1.0;
     if (lane < NB) { cx = L.col[lane]; if (lane >= K) v = fabs(cx.x) + fabs(cx.y); }
-    // single-precision keys decide unless two candidates round to the same float; then the exact comparison does
+    // single-precision keys decide unless two candidates round to the same float; then the exact comparison does.  The keys are
+    // non-negative floats (or -1 for the lanes that hold no candidate), so their order is the order of their bit patterns as signed
+    // integers: the scan is four v_max_i32 with a DPP row shift each (the float version cost a canonicalising v_max plus two moves per
+    // stage, 20 vector instructions instead of 4)
     const float kf = (float)v;
-    float mf = fmaxf(kf, dpp_f<0x111>(kf));
-    mf = fmaxf(mf, dpp_f<0x112>(mf));
-    mf = fmaxf(mf, dpp_f<0x114>(mf));
-    mf = fmaxf(mf, dpp_f<0x118>(mf));
-    const float vmaxf = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(mf), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mf), 31)));
-    unsigned long long hit = __ballot(kf == vmaxf);
+    int mi = __float_as_int(kf);
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(mi));
+    const int vmaxi = max(__builtin_amdgcn_readlane(mi, 15), __builtin_amdgcn_readlane(mi, 31));
+    unsigned long long hit = __ballot(__float_as_int(kf) == vmaxi);
     if (__builtin_popcountll(hit) != 1) {                        // wave-uniform, rare
         double m = fmax(v, dpp_d<0x111>(v));
         m = fmax(m, dpp_d<0x112>(m));
@@ -108,7 +112,7 @@ __device__ __forceinline__ void gauss_jordan_step(double2 (&q)[2][3], GreenLds& 
     rden = fma(rden, fma(-den, rden, 1.0), rden);
     rden = fma(rden, fma(-den, rden, 1.0), rden);
     const double2 ip = make_double2(pv.x * rden, -pv.y * rden);
-    const double2* prow = L.rowk;
+    double2* prow = L.rowk;
     if (p != K) {                                                // wave-uniform: rows K and p change places
         const int pig = p >> 1;
         const bool odd = p & 1, mine = act && igp == pig;
@@ -128,23 +132,25 @@ __device__ __forceinline__ void gauss_jordan_step(double2 (&q)[2][3], GreenLds& 
         }
         prow = L.rowp;
     }
+    // M'[i][j] = x[i][j] - f_i r_j with r = (pivot row, its entry K := 1) / pivot, f = column K with f_K := -1, x = M with row K and column K
+    // zeroed.  The two substitutions are made ONCE, in LDS, by one lane (a wave's LDS operations complete in order), and the zeroing is a
+    // multiplication by a 0 / 1 lane mask: one instruction per double where a select is two (round 4; the step was 114 vector instructions
+    // for 24 useful multiply-adds, tools/pmc_green.sh)
+    if (lane == 0) { prow[K] = make_double2(1.0, 0.0); L.col[K] = make_double2(-1.0, 0.0); }
+    wave_sync();
+    const double mrow = in_row ? 0.0 : 1.0, mcol = in_col ? 0.0 : 1.0, mboth = (in_row || in_col) ? 0.0 : 1.0;
     double2 r[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double2 rv = prow[3 * jg + c];
-        if (c == KC) rv = sel(in_col, make_double2(1.0, 0.0), rv);
-        r[c] = gmul(rv, ip);
-    }
+    for (int c = 0; c < 3; ++c) r[c] = gmul(prow[3 * jg + c], ip);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        double2 f = L.col[2 * ig + rr];
-        if (rr == KR) f = sel(in_row, make_double2(-1.0, 0.0), f);
+        const double2 f = L.col[2 * ig + rr];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double2 x = q[rr][c];
-            if (rr == KR && c == KC) x = sel(in_row || in_col, make_double2(0.0, 0.0), x);
-            else if (rr == KR) x = sel(in_row, make_double2(0.0, 0.0), x);
-            else if (c == KC) x = sel(in_col, make_double2(0.0, 0.0), x);
+            if (rr == KR && c == KC) x = make_double2(x.x * mboth, x.y * mboth);
+            else if (rr == KR) x = make_double2(x.x * mrow, x.y * mrow);
+            else if (c == KC) x = make_double2(x.x * mcol, x.y * mcol);
             q[rr][c] = cfms(f, r[c], x);
         }
     }
@@ -185,14 +191,23 @@ __device__ __forceinline__ void unpermute_from(double2 (&q)[2][3], GreenLds& L, 
     }
 }
 
-// A_l block of this lane and the lane's share of B_l (staged to LDS at the start of the level that uses them)
-__device__ __forceinline__ void green_fetch(double2 (&an)[2][3], double2 (&bn)[6], const double2* __restrict__ A, const double2* __restrict__ Bl, int lane, int ig, int jg) {
+// A_l block of this lane (fetched one level ahead: shared by all energies of the site, L2-resident)
+__device__ __forceinline__ void green_fetch(double2 (&an)[2][3], const double2* __restrict__ A, int ig, int jg) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int c = 0; c < 3; ++c) an[rr][c] = A[(2 * ig + rr) + NB * (3 * jg + c)];
+}
+// B_l straight into the wave's LDS slice (global_load_lds_dwordx4: lane i of load m writes element 64 m + i; no registers are held while
+// the elimination of the level runs -- the register copy this replaces was the kernel's 112 bytes of scratch per lane).  The products that
+// read L.B wait for it with vmcnt(0).
+__device__ __forceinline__ void green_stage_b(GreenLds& L, const double2* __restrict__ Bl, int lane) {
 #pragma unroll
-    for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; bn[m] = Bl[el < BLK ? el : 0]; }
+    for (int m = 0; m < 6; ++m) {
+        const int el = lane + 64 * m;
+        if (el < BLK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bl + el), (__attribute__((address_space(3))) void*)(L.B + 64 * m), 16, 0, 0);
+    }
 }
 
 // grid = (ceil(nen / GREEN_WAVES), nsites).  a_b, b_sqrt: [site][lld][324] complex; a_inf, b_inf: [site][324] real; g0: [site][nen][324]
@@ -240,9 +255,8 @@ __global__ __launch_bounds__(GREEN_WAVES * 64, GREEN_WAVES_PER_SIMD) void k_bloc
             q[rr][c] = x;
         }
     const double pr = e + (e != 0.0 ? eta_re : 0.0), pim = (e != 0.0 ? eta_im : 0.0);
-    // operands of a level are fetched one level ahead (they are shared by all energies of the site and L2-resident)
-    double2 an[2][3], bn[6];
-    if (lld > 1) green_fetch(an, bn, a_b + ((size_t)site * lld + (lld - 2)) * BLK, b_sqrt + ((size_t)site * lld + (lld - 2)) * BLK, lane, ig, jg);
+    double2 an[2][3];
+    if (lld > 1) green_fetch(an, a_b + ((size_t)site * lld + (lld - 2)) * BLK, ig, jg);
 #pragma unroll 1
     for (int l = lld - 1; l >= 1; --l) {
 #pragma unroll
@@ -252,11 +266,11 @@ __global__ __launch_bounds__(GREEN_WAVES * 64, GREEN_WAVES_PER_SIMD) void k_bloc
                 const bool dg = (2 * ig + rr) == (3 * jg + c);
                 q[rr][c] = make_double2((dg ? pr : 0.0) - an[rr][c].x - q[rr][c].x, (dg ? pim : 0.0) - an[rr][c].y - q[rr][c].y);
             }
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { const int el = lane + 64 * m; if (el < BLK) L.B[el] = bn[m]; }
-        if (l > 1) green_fetch(an, bn, a_b + ((size_t)site * lld + (l - 2)) * BLK, b_sqrt + ((size_t)site * lld + (l - 2)) * BLK, lane, ig, jg);
+        green_stage_b(L, b_sqrt + ((size_t)site * lld + (l - 1)) * BLK, lane);      // (the previous level's products have read L.B: wave_sync below)
+        if (l > 1) green_fetch(an, a_b + ((size_t)site * lld + (l - 2)) * BLK, ig, jg);
         gauss_jordan_from<0>(q, L, lane, ig, jg, act);
         unpermute_from<NB - 1>(q, L, ig, jg, act);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // B_l is in LDS
         // X = Q^-1 B
         if (act) {
 #pragma unroll
