@@ -154,7 +154,7 @@ struct rsrec_handle {
     std::vector<RegionEntry*> region_cache;
     int lattice_epoch = 0;
     const int* cur_order = nullptr;
-    const int* cur_cum = nullptr;     // [nrows][nlev] counts, followed by [nrows][nlev] list offsets
+    const int* cur_cum = nullptr;     // [nrows][nlev] counts, [nrows][nlev] list offsets (the lists of H|psi>), then the same two tables for the streaming passes
     const std::vector<int>* cur_level_max = nullptr;
     const std::vector<double>* cur_level_groups = nullptr;
     const std::vector<double>* cur_mult_hist = nullptr;
@@ -724,9 +724,18 @@ int plan_batch(rsrec_t* h, int nchains, int nvec, size_t vec_elems_per_chain, Ba
 int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, int napply, bool two_pass, bool grouped, int& ostride,
                    double& atom_steps, double& block_mults) {
     const int kk = h->kk;
-    // order row = [level-major list | spatially sorted list of ALL atoms]; each list padded into operator-class groups of 8 when grouped
-    const int cap = grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk;
-    ostride = 2 * cap;
+    // order row = [one list per level of the growing region, each sorted by (operator class, position) | the same for ALL atoms]; every
+    // list is padded into operator-class groups of 8 when grouped.  (Rounds 1-3 kept ONE level-major list -- shell after shell, a level's
+    // atoms a prefix of it -- which costs 4 bytes per atom and chain but walks a level shell by shell: the waves of an XCD then work on a band
+    // of one shell while the blocks they gather lie in the bands of the two neighbouring shells, handled elsewhere and at other times.
+    // Measured per launch on 64 x 22^3 / 46^3 (tools/per_level_pmc.sh, per_level_trace.sh): L2 hit rate 0.38-0.41 on the growing levels
+    // against 0.55 on the list of all atoms, 1.7x the fabric bytes and 1.5x the time per atom -- and on the 46^3 cell the regions grow for 26
+    // of the 49 levels.  A list per level, position-sorted as a whole, gives the growing region the locality of the saturated one.)
+    // The streaming passes behind H|psi> (Gram sums, orthogonalisation, moment sums) read every active block once and gather nothing: they keep
+    // the level-major list (shell after shell, each shell sorted by class and position; a level = a prefix), whose walk is closer to address
+    // order -- on the per-level lists k_mfma_orth3 was 2.8 % slower (46^3, same box).  row = [level-major | per level | all atoms].
+    const int cap = grouped ? kk + 7 * h->nmax + 7 * h->ntype + 8 : kk;          // capacity of one list of all atoms
+    const int cap_pre = ((grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk) + GROUP - 1) / GROUP * GROUP;   // capacity of the level-major list (a multiple of 8: every list starts on a group border)
     const int flags = (two_pass ? 1 : 0) | (grouped ? 2 : 0) | (nseed << 2);
     for (auto* e : h->region_cache)
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
@@ -734,12 +743,41 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             h->cur_order = e->order.as<int>(); h->cur_cum = e->cum.as<int>(); h->cur_nrows = nb; h->cur_level_max = &e->level_max; h->cur_level_groups = &e->level_groups;
             h->cur_mult_hist = &e->mult_hist;
             h->cur_entry = e;
+            ostride = e->ostride;
             atom_steps += e->atom_steps; block_mults += e->block_mults;
             return RSREC_OK;
         }
-    std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)2 * nb * nlev, 0);
-    std::vector<double> as(nb, 0.0), bm(nb, 0.0);
     const int ntau_h = h->nmax + h->ntype, nfs_h = h->nslots + 1;
+    const int sat_from = (int)(0.8 * kk);                        // regions of at least this many atoms run on the list of all atoms
+    // the regions first (a few short-lived host threads; see below), then the row size they need
+    std::vector<Region> regs(nb);
+    auto run_threads = [&](auto&& fn) {
+        const int nthr = std::max(1, std::min({nb, 8, (int)std::thread::hardware_concurrency()}));
+        if (nthr == 1) { for (int c = 0; c < nb; ++c) fn(c); return; }
+        std::atomic<int> next_chain{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; ++t)
+            pool.emplace_back([&]() { for (int c = next_chain++; c < nb; c = next_chain++) fn(c); });
+        for (auto& th : pool) th.join();
+    };
+    run_threads([&](int c) { grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, regs[c]); });
+    size_t lvneed = 8;
+    for (int c = 0; c < nb; ++c) {
+        size_t need = 0;
+        for (int L = 0; L < nlev; ++L) {
+            const int n = regs[c].cum[L];
+            if (n >= sat_from || (L > 0 && n == regs[c].cum[L - 1])) continue;       // list of all atoms / the previous level's list again
+            need += (size_t)n + (grouped ? (size_t)7 * std::min(ntau_h, n) + 8 : 0);
+        }
+        lvneed = std::max(lvneed, need);
+    }
+    lvneed = (lvneed + 7) / 8 * 8;
+    if (lvneed + (size_t)cap > (size_t)INT32_MAX) return fail(h, RSREC_ERR_ARG, "region lists of %zu entries per chain exceed the index range", lvneed + (size_t)cap);
+    if ((size_t)cap_pre + lvneed + (size_t)cap > (size_t)INT32_MAX) return fail(h, RSREC_ERR_ARG, "region lists of %zu entries per chain exceed the index range", (size_t)cap_pre + lvneed + (size_t)cap);
+    const int sat_off = cap_pre + (int)lvneed;
+    ostride = sat_off + cap;
+    std::vector<int> order((size_t)nb * ostride, -1), cum((size_t)4 * nb * nlev, 0);      // counts, offsets (H|psi>); counts, offsets (streaming passes)
+    std::vector<double> as(nb, 0.0), bm(nb, 0.0);
     const size_t hist_n = (size_t)2 * ntau_h * nfs_h;
     std::vector<double> hist((size_t)nb * hist_n, 0.0);
     auto tau = [&](int i) { return i < h->nmax ? i : h->nmax + h->iz0[i]; };
@@ -764,28 +802,43 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     // One region per chain, built by a few short-lived host threads.  (Not OpenMP: its idle workers spin for 200 ms after a
     // parallel region -- one per visible CPU, 256 on the GPU boxes -- and burn the process's CPU quota: the host thread was then
     // descheduled for 60-90 ms at a time during the next two or three calls, inside whatever HIP call it happened to be in.)
+    std::vector<double> lgroups((size_t)nb * nlev * ntau_h, 0.0);     // [chain][level][class]: groups of the level's own list
     auto build_chain = [&](int c) {
-        Region R;
-        grow_region(h, seeds0 + (size_t)c * nseed, nseed, nlev, R);
+        const Region& R = regs[c];
         int* orow = order.data() + (size_t)c * ostride;
         int* crow = cum.data() + (size_t)c * nlev;
         int* brow = cum.data() + (size_t)(nb + c) * nlev;
-        std::copy(sat_list.begin(), sat_list.end(), orow + cap);
-        int w = 0;
-        std::vector<int> lev;
+        int* crow2 = cum.data() + (size_t)(2 * nb + c) * nlev;
+        int* brow2 = cum.data() + (size_t)(3 * nb + c) * nlev;
+        std::copy(sat_list.begin(), sat_list.end(), orow + sat_off);
+        int w = cap_pre, wp = 0;
+        std::vector<int> lev, region, merged;
         for (int L = 0; L < nlev; ++L) {
             const int lo = L ? R.cum[L - 1] : 0, hi = R.cum[L];
+            // once the region covers most of the lattice the sorted list of all atoms is used instead: blocks outside
+            // the region are exactly zero, so a superset changes nothing
+            if (hi >= sat_from) { crow[L] = crow2[L] = sat_count; brow[L] = brow2[L] = sat_off; continue; }
             lev.assign(R.order.begin() + lo, R.order.begin() + hi);
             std::sort(lev.begin(), lev.end(), before);
-            for (size_t q = 0; q < lev.size(); ++q) {
-                if (grouped && q > 0 && tau(lev[q]) != tau(lev[q - 1])) while (w % GROUP) orow[w++] = -1;
-                orow[w++] = lev[q];
+            for (size_t q = 0; q < lev.size(); ++q) {            // level-major list: this shell behind the earlier ones
+                if (grouped && q > 0 && tau(lev[q]) != tau(lev[q - 1])) while (wp % GROUP) orow[wp++] = -1;
+                orow[wp++] = lev[q];
+            }
+            if (grouped) while (wp % GROUP) orow[wp++] = -1;
+            crow2[L] = wp; brow2[L] = 0;
+            if (L > 0 && hi == lo) { crow[L] = crow[L - 1]; brow[L] = brow[L - 1]; continue; }     // the region has stopped growing: the previous level's list again
+            merged.resize(region.size() + lev.size());
+            std::merge(region.begin(), region.end(), lev.begin(), lev.end(), merged.begin(), before);
+            region.swap(merged);
+            brow[L] = w;
+            double* G = lgroups.data() + ((size_t)c * nlev + L) * ntau_h;
+            for (size_t q = 0; q < region.size(); ++q) {
+                if (grouped && q > 0 && tau(region[q]) != tau(region[q - 1])) while (w % GROUP) orow[w++] = -1;
+                if (w % GROUP == 0) G[grouped ? tau(region[q]) : 0] += 1.0;
+                orow[w++] = region[q];
             }
             if (grouped) while (w % GROUP) orow[w++] = -1;
-            // once the region covers most of the lattice the spatially sorted list of all atoms is used instead: blocks outside
-            // the region are exactly zero, so a superset changes nothing, and neighbouring groups then share their gathers in L2
-            if (R.cum[L] >= (int)(0.8 * kk)) { crow[L] = sat_count; brow[L] = cap; }
-            else { crow[L] = w; brow[L] = 0; }
+            crow[L] = w - brow[L];
         }
         // bookkeeping in the reference's terms: application t (1..napply) multiplies one block per (atom, slot) whose
         // source atom lies in the region before it; post-hop work runs on the region after it.
@@ -827,18 +880,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         if (two_pass) for (int t2 = 0; t2 < ntau_h; ++t2) b_m += H[((size_t)ntau_h + t2) * nfs_h + ns];       // the reference multiplies enim and lsham separately
         as[c] = a_s; bm[c] = b_m;
     };
-    {
-        const int nthr = std::max(1, std::min({nb, 8, (int)std::thread::hardware_concurrency()}));
-        if (nthr == 1) {
-            for (int c = 0; c < nb; ++c) build_chain(c);
-        } else {
-            std::atomic<int> next_chain{0};
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; ++t)
-                pool.emplace_back([&]() { for (int c = next_chain++; c < nb; c = next_chain++) build_chain(c); });
-            for (auto& th : pool) th.join();
-        }
-    }
+    run_threads(build_chain);
     double as_sum = 0.0, bm_sum = 0.0;
     for (int c = 0; c < nb; ++c) { as_sum += as[c]; bm_sum += bm[c]; }
     atom_steps += as_sum; block_mults += bm_sum;
@@ -865,9 +907,9 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     e->level_groups.assign((size_t)nlev * ntau_h, 0.0);
     {
         // groups by operator class: the saturated list is the same for every chain; a level-major list is walked once per chain
-        std::vector<double> sat_hist(ntau_h, 0.0), run(ntau_h, 0.0);
+        std::vector<double> sat_hist(ntau_h, 0.0);
         for (int g = 0; g < sat_count / GROUP; ++g) sat_hist[tau(sat_list[(size_t)g * GROUP])] += 1.0;
-        e->sat_base = cap;
+        e->sat_base = sat_off;
         e->level_sat.assign(nlev, 0);
         if (grouped)
             for (int g = 0; g < sat_count / GROUP; ++g) {
@@ -876,16 +918,17 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
                 else e->sat_runs.back().hi = g + 1;
             }
         for (int c = 0; c < nb; ++c) {
-            const int* orow = order.data() + (size_t)c * ostride;
-            std::fill(run.begin(), run.end(), 0.0);
-            int g = 0;
+            const double* prev = nullptr;
             for (int l = 0; l < nlev; ++l) {
                 const int cnt = cum[(size_t)c * nlev + l];
                 e->level_max[l] = std::max(e->level_max[l], cnt);
-                const bool sat = cum[(size_t)(nb + c) * nlev + l] != 0;
+                const bool sat = cum[(size_t)(nb + c) * nlev + l] == sat_off;   // (level_max: the larger of the two lists' counts sizes the launches)
+                e->level_max[l] = std::max(e->level_max[l], cum[(size_t)(2 * nb + c) * nlev + l]);
                 if (sat) e->level_sat[l] += 1;
-                if (!sat) for (; g < cnt / GROUP; ++g) run[grouped ? tau(orow[(size_t)g * GROUP]) : 0] += 1.0;
-                for (int t2 = 0; t2 < ntau_h; ++t2) e->level_groups[(size_t)l * ntau_h + t2] += sat ? sat_hist[t2] : run[t2];
+                const double* G = lgroups.data() + ((size_t)c * nlev + l) * ntau_h;
+                if (!sat && l > 0 && cum[(size_t)(nb + c) * nlev + l] == cum[(size_t)(nb + c) * nlev + l - 1] && prev) G = prev;     // the previous level's list again
+                for (int t2 = 0; t2 < ntau_h; ++t2) e->level_groups[(size_t)l * ntau_h + t2] += sat ? sat_hist[t2] : G[t2];
+                prev = sat ? nullptr : G;
             }
         }
     }
@@ -1287,6 +1330,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
 
         ChainView CV;
         CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        ChainView CVp = CV;                                   // the streaming passes walk the level-major lists (upload_regions)
+        CVp.cum = h->cur_cum + (size_t)2 * h->cur_nrows * nlev; CVp.obase = h->cur_cum + (size_t)3 * h->cur_nrows * nlev;
         // Everything from here to the coefficients' download is stream work only (kernels, memsets, cross-stream events): for small
         // batches it is captured ONCE as a HIP graph and replayed by every later call with the same lattice, seeds, depth and buffers
         // (each SCF iteration of the reference: recur_b on the same <= 4 sites) -- 49 levels x 6-8 dependent launches otherwise cost
@@ -1349,12 +1394,12 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                     }
                     e1 = next_event(h);
                     const dim3 gl = level_grid(h, grid_mf, lv_final);
-                    k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, psi, hpsi, gpartial);
+                    k_mfma_adot<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, psi, hpsi, gpartial);
                     { int n2 = gl.x; const double* p2 = presum(h, gpartial, nb, n2, 1296);
                       rc = wait_b_level(); if (rc) return rc;
                       k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
-                    if (h->opt_orth3 == 2) k_mfma_orth3w<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                else k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                    if (h->opt_orth3 == 2) k_mfma_orth3w<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                else k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
                     rc = reduce_b_level(gl.x, ll); if (rc) return rc;
                     std::swap(psi, t2);
                     hop_ev.emplace_back(e0, e1);
@@ -2109,6 +2154,8 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         h->t_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
         ChainView CV;
         CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
+        ChainView CVp = CV;                                   // the streaming moment pass walks the level-major lists (upload_regions)
+        CVp.cum = h->cur_cum + (size_t)2 * h->cur_nrows * nlev; CVp.obase = h->cur_cum + (size_t)3 * h->cur_nrows * nlev;
         for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
         double* p0 = h->d_vec[0].as<double>();
@@ -2151,10 +2198,10 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
                 double* gp = h->d_partial.as<double>();
                 if (red_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_bred, 0)); red_pending = false; }   // gp is free again
                 if (fused) {
-                    if (first) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
-                    else k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
-                } else if (first) k_mfma_cheb<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
-                else k_mfma_cheb<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CV, lv_final, kk, tmp, src, p0, dst, a, b, gp);
+                    if (first) k_mfma_cheb<true, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
+                    else k_mfma_cheb<false, true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, nullptr, src, nullptr, dst, a, b, gp);
+                } else if (first) k_mfma_cheb<true><<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, tmp, src, nullptr, dst, a, b, gp);
+                else k_mfma_cheb<false><<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, tmp, src, p0, dst, a, b, gp);
                 hipStream_t rs = h->stream;
                 if (side) {
                     HIPCK(h, hipEventRecord(h->ev_orth, h->stream));
