@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--lld", type=int, default=50)
     ap.add_argument("--recur", choices=("block", "chebyshev"), default=None, help="default: block (chebyshev for --workload fccCu001)")
     ap.add_argument("--cond-ll", type=int, default=50, help="--workload kubo: moment orders per side")
+    ap.add_argument("--vectors", type=int, default=1, help="--workload kubo: vectors per step (the library advances up to 8 together as the chains of one launch)")
     ap.add_argument("--workload", choices=("bcc", "fccCu001", "B2FeCo", "kubo"), default="bcc", help="bcc: synthetic periodic bcc Fe supercell (--cells); others: lattices of the reference's own cases")
     ap.add_argument("--hoh", action="store_true")
     ap.add_argument("--spin-mixing", action="store_true", help="stencil rotated into a tilted spin frame: spin-flip entries in every block")
@@ -226,7 +227,7 @@ def main_kubo(args):
     import torch
     torch.cuda.set_device(0)
     z = load_golden("fccPt_kubo_hoh" if args.hoh else "fccPt_kubo")
-    n, cond_ll = args.cells, args.cond_ll
+    n, cond_ll, nvec = args.cells, args.cond_ll, max(1, args.vectors)
     nn = bcc_supercell((n, n, n), z["slot_vec"], primitive=np.array(FCC_PRIMITIVE))
     kk, nb = nn.shape[0], int(nn[0, 0])
     a, b = float(z["acheb"]), float(z["bcheb"])
@@ -240,7 +241,7 @@ def main_kubo(args):
     vo = dict(vo_a=z.get("vo_a"), vo_b=z.get("vo_b")) if args.hoh else {}
 
     def step():
-        return rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, atlist=np.array([1], np.int32), **vo)
+        return rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, atlist=np.arange(1, nvec + 1, dtype=np.int32), **vo)
 
     for _ in range(args.warmup):
         step()
@@ -255,7 +256,7 @@ def main_kubo(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert np.isfinite(mu).all()
-    gemm_flop = 8.0 * (cond_ll * 18.0) ** 2 * kk * 18.0 * args.steps                 # L^H R over the (atom, row) index: complex MACs x 8
+    gemm_flop = 8.0 * (cond_ll * 18.0) ** 2 * kk * 18.0 * args.steps * nvec          # L^H R over the (atom, row) index: complex MACs x 8
     spmm_alg = FLOP_PER_BLOCK_MULT * acc["block_multiplies"]
     hop_s, gemm_s = acc["hop_ms"] * 1e-3, acc["rest_ms"] * 1e-3
     achieved = acc["hop_required_flop"] / hop_s * 1e-12
@@ -264,10 +265,10 @@ def main_kubo(args):
         "value": (spmm_alg + gemm_flop) / elapsed * 1e-9, "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic periodic fcc lattice; Pt spd blocks and velocity operators (v_a, v_b%s) dumped from the reference's conductivity/fccPt case" % (", vo_a, vo_b" if args.hoh else ""),
-        "config": {"workload": "fcc Pt %d^3 = %d atoms, nsp=2 18x18 blocks, %sstochastic Kubo moments cond_ll=%d (%d x %d blocks of 18x18), one vector per step" % (n, kk, "hoh " if args.hoh else "", cond_ll, cond_ll, cond_ll),
-                   "workload_key": "kubo%s_c%d_l%d" % ("_hoh" if args.hoh else "", n, cond_ll), "atoms": kk, "cond_ll": cond_ll, "neighbour_slots": nb,
+        "config": {"workload": "fcc Pt %d^3 = %d atoms, nsp=2 18x18 blocks, %sstochastic Kubo moments cond_ll=%d (%d x %d blocks of 18x18), %d vector%s per step" % (n, kk, "hoh " if args.hoh else "", cond_ll, cond_ll, cond_ll, nvec, "" if nvec == 1 else "s"),
+                   "workload_key": "kubo%s_c%d_l%d%s" % ("_hoh" if args.hoh else "", n, cond_ll, "" if nvec == 1 else "_v%d" % nvec), "atoms": kk, "cond_ll": cond_ll, "vectors_per_step": nvec, "neighbour_slots": nb,
                    "parallelism": "single GPU (the vectors of a run shard over ranks like recursion sites)", "collective": None},
-        "vectors_per_s": args.steps / elapsed,
+        "vectors_per_s": args.steps * nvec / elapsed, "ms_per_vector": elapsed / (args.steps * nvec) * 1e3,
         "device_ms_per_step": acc["total_ms"] / args.steps,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "frac_kernel": achieved / FP64_PEAK_TFLOPS,
                      "frac_step": (acc["hop_required_flop"] + gemm_flop) / elapsed * 1e-12 / FP64_PEAK_TFLOPS,

@@ -558,6 +558,154 @@ __device__ __forceinline__ void s5_run_stream(S5Acc& acc, const int* __restrict_
 #undef S5_STEP
 }
 
+
+// ---- split tasks (NSP = 3; LDS / persistent form): one wave = (group of 8 atoms, output spin, THIRD of the nine tiles) ----------------------
+// A wave of the form above holds the nine tiles of a group for ~75 us; the 256 waves of an XCD are then spread over 1 024 atoms whose
+// neighbourhood (9 MB) does not fit the XCD's 4 MB L2, and two 236-register waves per SIMD are all that can cover each other's stalls.
+// Here a task is three tiles of a group -- part 0: atoms 0..2, part 1: atoms 3..5, part 2: atoms 6, 7 and the remainder tile (columns 16, 17 of
+// all eight atoms) -- with 30 accumulator registers and three small operand sets: the waves of an XCD work on a third as many atoms per wave,
+// and four waves fit a SIMD.  Every tile is accumulated exactly as in the nine-tile wave (same k order): results are bitwise the same.
+template <int NT> struct S5PairN { s5_d2 b[NT]; s5_d2 a[2]; };
+template <int NT> struct S5SingleN { double b[NT]; double a[2]; };
+template <int NT> struct S5AccN { double4_t m[NT]; double r[NT]; };
+
+template <int NT>
+__device__ __forceinline__ void s5_mfma_n(S5AccN<NT>& acc, const S5PairN<NT>& o) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0][e], o.b[t][e], acc.m[t], 0, 0, 0);
+            acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1][e], o.b[t][e], acc.r[t], 0, 0, 0);
+        }
+    s5_interleave<NT, 4 * NT>();
+}
+template <int NT>
+__device__ __forceinline__ void s5_mfma_n(S5AccN<NT>& acc, const S5SingleN<NT>& o) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc.m[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[0], o.b[t], acc.m[t], 0, 0, 0);
+        acc.r[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(o.a[1], o.b[t], acc.r[t], 0, 0, 0);
+    }
+    s5_interleave<NT, 2 * NT>();
+}
+
+struct S5EntN { unsigned off[3]; unsigned rem; };
+
+// NMAIN atom tiles (wave-uniform neighbour blocks) + (HASREM) the remainder tile of the whole group (ratom: its eight atoms)
+template <bool TWO, int NMAIN, bool HASREM>
+__device__ __forceinline__ void s5_run_stream_n(S5AccN<NMAIN + (HASREM ? 1 : 0)>& acc, const int* __restrict__ meta, const char* __restrict__ fr /*the staged stream in LDS*/,
+                                                const char* __restrict__ inb, const char* __restrict__ in2b, const int* __restrict__ nbr5,
+                                                const int (&atom)[NMAIN], const int (&ratom)[GROUP], int rem_sel, int ncol, int sig, int l4,
+                                                unsigned lane_main, unsigned lane_z, unsigned lane_rem, unsigned lane_rem_z, unsigned lane16, unsigned lane8) {
+    constexpr int NT = NMAIN + (HASREM ? 1 : 0);
+    int left = meta[0];
+    int ebase = 0, tbase = 0;
+    bool first = true;
+    if (left <= 0) return;
+    const bool extras = TWO && meta[1] != 0;
+    const S5_CONST int* codes = (const S5_CONST int*)(meta + 2);
+    const S5_CONST int* nbr = (const S5_CONST int*)nbr5;
+    S5EntN E0, E1;
+    int raw[NMAIN], rraw[GROUP];
+    int code_cur = codes[ebase], code_nxt = codes[ebase + 1];
+    auto load_idx = [&](int col) {
+#pragma unroll
+        for (int t = 0; t < NMAIN; ++t) raw[t] = nbr[(size_t)ncol * atom[t] + col];
+        if constexpr (HASREM) {
+#pragma unroll
+            for (int t = 0; t < GROUP; ++t) rraw[t] = nbr[(size_t)ncol * ratom[t] + col];
+        }
+    };
+    load_idx(code_cur & 255);
+    unsigned vlane_main = lane_main, vlane_z = lane_z, vlane16 = lane16, vlane8 = lane8;
+    auto open_entry = [&](int j, S5EntN& E) {
+        const unsigned so = 2592u * (unsigned)((code_cur >> 8) ? 1 - sig : sig);
+#pragma unroll
+        for (int t = 0; t < NMAIN; ++t) E.off[t] = (unsigned)raw[t] * (BLD * 8u) + so;
+        if constexpr (HASREM) {
+            const int r01 = (rem_sel & 1) ? rraw[1] : rraw[0], r23 = (rem_sel & 1) ? rraw[3] : rraw[2], r45 = (rem_sel & 1) ? rraw[5] : rraw[4], r67 = (rem_sel & 1) ? rraw[7] : rraw[6];
+            const int r03 = (rem_sel & 2) ? r23 : r01, r47 = (rem_sel & 2) ? r67 : r45;
+            E.rem = (unsigned)((rem_sel & 4) ? r47 : r03) * (BLD * 8u) + so;
+        }
+        code_cur = code_nxt;
+        code_nxt = codes[j + 2];
+        load_idx(code_cur & 255);
+    };
+    auto issue = [&](auto s2c, auto& o) {
+        constexpr int S2 = decltype(s2c)::value, S = S2 % 27, wrap = S2 / 27;
+        using I = S5St<S>;
+        S5EntN& EA = (I::eA & 1) ? E1 : E0;
+        S5EntN& EB = (I::eA & 1) ? E0 : E1;
+        if constexpr (I::opens) open_entry(ebase + 10 * wrap + I::eOpen, (I::eOpen & 1) ? E1 : E0);
+        const bool head = wrap == 0 && first && extras;
+        const char* __restrict__ base = (TWO && S < 5 && head) ? in2b : inb;
+        constexpr unsigned rowA = 288u * I::mA0, rowB = 0u - 288u * I::sp;
+        unsigned& lm = I::K < 2 ? vlane_main : vlane_z;
+        unsigned& lf = I::K < 2 ? vlane16 : vlane8;
+        const unsigned lr = I::K < 2 ? lane_rem : lane_rem_z;
+        asm volatile("" : "+v"(lm));
+        asm volatile("" : "+v"(lf));
+        using V = std::remove_reference_t<decltype(o.b[0])>;
+        if constexpr (!I::straddle) {
+#pragma unroll
+            for (int t = 0; t < NMAIN; ++t) {
+                s5_gp pt = (s5_gp)base + EA.off[t];
+                asm("" : "+s"(pt));
+                o.b[t] = *(const S5_GLOBAL V*)(pt + lm + rowA);
+            }
+            if constexpr (HASREM) o.b[NMAIN] = *(const S5_GLOBAL V*)((s5_gp)base + (EA.rem + lr) + rowA);
+        } else {
+            const bool inB = (I::K < 2 ? l4 : (l4 >> 1)) >= I::sp;
+#pragma unroll
+            for (int t = 0; t < NMAIN; ++t) {
+                const unsigned off = (inB ? EB.off[t] + rowB : EA.off[t] + rowA) + lm;
+                o.b[t] = *(const S5_GLOBAL V*)((s5_gp)base + off);
+            }
+            if constexpr (HASREM) {
+                const unsigned off = (inB ? EB.rem + rowB : EA.rem + rowA) + lr;
+                o.b[NMAIN] = *(const S5_GLOBAL V*)((s5_gp)base + off);
+            }
+        }
+        const S5_LDS char* fl = (const S5_LDS char*)fr + (unsigned)(tbase + 9 * wrap + I::T) * S5_TRIPLE_BYTES + (I::K == 0 ? 0 : I::K == 1 ? 2048 : 4096);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) o.a[q] = *(const S5_LDS V*)(fl + lf + q * (I::K < 2 ? 1024 : 512));
+    };
+    // operands FIVE steps ahead in six register sets (two banks of X, Y, Z): a step of three tiles is 480 matrix cycles, and two steps of
+    // them would not cover a gather that misses L2.  The set of step S + 5 is the one step S - 1 consumed; the 27-step period is odd, so
+    // two periods are unrolled for the set names to repeat.
+    S5PairN<NT> X0, Y0, X1, Y1;
+    S5SingleN<NT> Z0, Z1;
+    issue(S5C<0>{}, X0);
+    issue(S5C<1>{}, Y0);
+    issue(S5C<2>{}, Z0);
+    issue(S5C<3>{}, X1);
+    issue(S5C<4>{}, Y1);
+    // (one exit per step -- so that a step is reachable only through the step before it and the compiler's vmcnt bookkeeping need not
+    // assume that the steps between a request and its use were skipped: it emits vmcnt(2..3) where 14 loads may stay in flight -- made the
+    // register allocator spill 9 KB per lane, as it did for the nine-tile wave)
+#define S5_STEP(S, NEXT, CUR)                 \
+    if (left > (S)) {                         \
+        issue(S5C<(S) + 5>{}, NEXT);          \
+        s5_mfma_n<NT>(acc, CUR);              \
+        __builtin_amdgcn_sched_barrier(0);    \
+    }
+    for (;; left -= 54) {
+        S5_STEP(0, Z1, X0) S5_STEP(1, X0, Y0) S5_STEP(2, Y0, Z0) S5_STEP(3, Z0, X1) S5_STEP(4, X1, Y1) S5_STEP(5, Y1, Z1)
+        S5_STEP(6, Z1, X0) S5_STEP(7, X0, Y0) S5_STEP(8, Y0, Z0) S5_STEP(9, Z0, X1) S5_STEP(10, X1, Y1) S5_STEP(11, Y1, Z1)
+        S5_STEP(12, Z1, X0) S5_STEP(13, X0, Y0) S5_STEP(14, Y0, Z0) S5_STEP(15, Z0, X1) S5_STEP(16, X1, Y1) S5_STEP(17, Y1, Z1)
+        S5_STEP(18, Z1, X0) S5_STEP(19, X0, Y0) S5_STEP(20, Y0, Z0) S5_STEP(21, Z0, X1) S5_STEP(22, X1, Y1) S5_STEP(23, Y1, Z1)
+        S5_STEP(24, Z1, X0) S5_STEP(25, X0, Y0) S5_STEP(26, Y0, Z0) S5_STEP(27, Z0, X1) S5_STEP(28, X1, Y1) S5_STEP(29, Y1, Z1)
+        S5_STEP(30, Z1, X0) S5_STEP(31, X0, Y0) S5_STEP(32, Y0, Z0) S5_STEP(33, Z0, X1) S5_STEP(34, X1, Y1) S5_STEP(35, Y1, Z1)
+        S5_STEP(36, Z1, X0) S5_STEP(37, X0, Y0) S5_STEP(38, Y0, Z0) S5_STEP(39, Z0, X1) S5_STEP(40, X1, Y1) S5_STEP(41, Y1, Z1)
+        S5_STEP(42, Z1, X0) S5_STEP(43, X0, Y0) S5_STEP(44, Y0, Z0) S5_STEP(45, Z0, X1) S5_STEP(46, X1, Y1) S5_STEP(47, Y1, Z1)
+        S5_STEP(48, Z1, X0) S5_STEP(49, X0, Y0) S5_STEP(50, Y0, Z0) S5_STEP(51, Z0, X1) S5_STEP(52, X1, Y1) S5_STEP(53, Y1, Z1)
+        if (left <= 54) break;
+        ebase += 20; tbase += 18; first = false;
+    }
+#undef S5_STEP
+}
+
 // One wave = (group of 8 atoms, output spin).  Input and output vectors in the CI layout.
 // !LDSA: workgroup = 8 waves = 4 groups x 2 spins; waves w and w + 4 (same group, different spin) land on the same SIMD; the operator
 //        fragments are global loads (L2-resident tables).
@@ -577,8 +725,9 @@ struct S5Epilogue { int kind = 0; const double* cur = nullptr; const double* old
 // batch -- blockIdx.y counts octets of chains, the groups are the run [run_lo, run_hi) of the class-sorted list of all atoms, which
 // every chain of the launch must be on (the host launches this form only then).  Chains share an atom's fragments the way 8 atoms of a
 // type do; as groups of their own such atoms fill one tile of nine.
-template <bool TWO, bool LDSA, bool OCT = false>
-__global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
+// NSP = 3 (LDS / persistent form only): split tasks -- a wave takes a third of a group's tiles (s5_run_stream_n); up to 16 waves per workgroup.
+template <bool TWO, bool LDSA, bool OCT = false, int NSP = 1>
+__global__ __launch_bounds__(NSP == 3 ? 768 : S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const int* __restrict__ order_all, const int* __restrict__ cum,
                                                const int* __restrict__ nbr /*nbr5: (kk+1) x (nslots+2)*/,
                                                const int* __restrict__ izp, const double* __restrict__ frag, const int* __restrict__ meta, int ntr,
                                                const double* __restrict__ in_all, double* __restrict__ out_all,
@@ -611,7 +760,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
         // all loads of a thread in flight at once (a rolled loop paid one memory latency per iteration: the copy then cost more than
         // the LDS reads save, because a workgroup lives for one round of groups only)
         const int n = ntr * (S5_TRIPLE / 2);
-        constexpr int PER = (int)(160 * 1024 / 16 / (S5_WG_GROUPS * 64));      // 40: the LDS limit over the threads of a 4-wave workgroup
+        constexpr int PER = (int)(160 * 1024 / 16 / (NSP == 3 ? 512 : S5_WG_GROUPS * 64));      // 40: the LDS limit over the threads of a 4-wave workgroup (split tasks: workgroups of 8 waves or more)
         const int nthr = (int)blockDim.x;
         s5_d2 v[PER];
 #pragma unroll
@@ -702,7 +851,12 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
     // (issuing the pull for the NEXT group before the current group's work was tried: the returning atomic is the oldest entry of the
     // in-order vmcnt queue and every operand wait of the first steps then waits for it as well -- 19 % slower)
     // (round 3: the pull issued right after the group's last operands were consumed, its round trip under the result stores: +1.5 %)
-    for (;; g += gstep) {
+    int part = 0;                                           // NSP = 3: the third of the group's tiles this task covers
+    auto next_task = [&]() {                                // static assignment: the parts of a group one after the other, then the wave's next group
+        if (NSP == 3 && !dynamic && part < 2) { ++part; return; }
+        part = 0; g += gstep;
+    };
+    for (;; next_task()) {
         int kpart = 0;
         if (dynamic) {
             int gi = 0;
@@ -711,6 +865,7 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
 #if RSREC_S5_KSPLIT_PROBE
             kpart = gi & 1; gi >>= 1;
 #endif
+            if constexpr (NSP == 3) { const unsigned gu = (unsigned)gi, gq = gu / 3u; part = (int)(gu - 3u * gq); gi = (int)gq; }
             g = glo + gi;
         }
         if (g >= gend) break;
@@ -721,6 +876,85 @@ __global__ __launch_bounds__(S5_WG_GROUPS * 128) void k_spmm5(SpmmDims D, const 
             if (skip) continue;
         }
         const int* __restrict__ grp = order + (size_t)g * GROUP;
+        if constexpr (NSP == 3) {
+            static_assert(NSP != 3 || (LDSA && !OCT), "split tasks: LDS / persistent form only");
+            const int g0 = grp[0];
+            const int first3 = g0 >= 0 ? g0 : zero_block;
+            if (D.skip_pa && first3 < D.nmax) continue;
+            const int tau3 = first3 < D.nmax ? first3 : D.nmax + izp[first3];
+            const int* __restrict__ M3 = meta + (size_t)tau3 * Spmm5Operator::META;
+            const char* __restrict__ fr3 = reinterpret_cast<const char*>(s5_lds);
+            S5AccN<3> acc3;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { acc3.m[t] = (double4_t){0, 0, 0, 0}; acc3.r[t] = 0.0; }
+            // result tiles -> memory (as `finish` below): tile i belongs to block av[i]; REM: tile 2 is the remainder tile (av[2] per lane)
+            auto finish3 = [&](auto remc, const int (&av)[3]) {
+                constexpr bool REM = decltype(remc)::value;
+                size_t eo[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) eo[i] = (size_t)BLD * av[i] + 324 * sig + ((REM && i == 2) ? 32 + 2 * (l15 & 1) : 2 * l15);
+                s5_d2 ec[3][2], ez[3][2];
+                double ecr[3], ezr[3];
+                if (epi.kind) {
+                    const double* cb = epi.cur + vo;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) ec[i][p] = *reinterpret_cast<const s5_d2*>(cb + eo[i] + 36 * (4 * p + l4));
+                        ecr[i] = cb[eo[i] + 288 + (l4 & 1)];
+                    }
+                    if (epi.kind == 2) {
+                        const double* zb = epi.old + vo;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) ez[i][p] = *reinterpret_cast<const s5_d2*>(zb + eo[i] + 36 * (4 * p + l4));
+                            ezr[i] = zb[eo[i] + 288 + (l4 & 1)];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int a = av[i];
+                    double* ob = out + eo[i];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        s5_d2 v; v[0] = acc3.m[i][2 * p]; v[1] = acc3.m[i][2 * p + 1];
+                        if (epi.kind) {
+                            v[0] = (v[0] - epi.b * ec[i][p][0]) / epi.a; v[1] = (v[1] - epi.b * ec[i][p][1]) / epi.a;
+                            if (epi.kind == 2) { v[0] = v[0] * 2.0 - ez[i][p][0]; v[1] = v[1] * 2.0 - ez[i][p][1]; }
+                        }
+                        if (a != zero_block) *reinterpret_cast<s5_d2*>(ob + 36 * (4 * p + l4)) = v;
+                    }
+                    double r = acc3.r[i];
+                    if (epi.kind) {
+                        r = (r - epi.b * ecr[i]) / epi.a;
+                        if (epi.kind == 2) r = r * 2.0 - ezr[i];
+                    }
+                    if (a != zero_block && l4 < 2) ob[288 + l4] = r;
+                }
+            };
+            int ratom[GROUP];
+            if (part < 2) {
+                int a3[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const int a = grp[3 * part + j]; a3[j] = a >= 0 ? a : zero_block; }
+#pragma unroll
+                for (int t = 0; t < GROUP; ++t) ratom[t] = zero_block;
+                s5_run_stream_n<TWO, 3, false>(acc3, M3, fr3, inb, in2b, nbr, a3, ratom, 0, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
+                finish3(std::false_type{}, a3);
+            } else {
+#pragma unroll
+                for (int t = 0; t < GROUP; ++t) { const int a = grp[t]; ratom[t] = a >= 0 ? a : zero_block; }
+                const int a2[2] = {ratom[6], ratom[7]};
+                int mra = grp[l15 >> 1];
+                mra = mra >= 0 ? mra : zero_block;
+                s5_run_stream_n<TWO, 2, true>(acc3, M3, fr3, inb, in2b, nbr, a2, ratom, l15 >> 1, ncol, sig, l4, lane_main, lane_z, lane_rem, lane_rem_z, lane16, lane8);
+                const int av[3] = {a2[0], a2[1], mra};
+                finish3(std::true_type{}, av);
+            }
+            continue;
+        }
         int atom[GROUP];                                    // padding entries (-1) become the zero block: no predicates in the step loop
         int vatom[GROUP], tile_blk[GROUP];                  // OCT: block index of tile t's own atom seen from chain c0's vectors; its neighbour blocks' shift
         int my_rem_atom, rem_blk = 0;

@@ -99,6 +99,7 @@ struct rsrec_handle {
     DevBuf d_asm[2][2], d_asm_in;
     std::vector<double> asm_host[2][2];
     int asm_nslots[2] = {0, 0}, asm_ncls[2] = {0, 0}, asm_hoh[2] = {0, 0};
+    double n_kubo_chain_launches = 0;   // rsrec_kubo_moments: whole-lattice products of the last call (launches x vectors in flight)
     int n_octet_launch = 0;      // launches of the last call that formed the groups of per-atom-block atoms over 8 chains (k_spmm5<., false, true>)
     int n_asm_reused = 0;        // block arrays the last rsrec_set_hamiltonian took from those device copies (0..4)
     long n_asm_calls = 0, n_ldos_calls = 0, n_recursion_calls = 0;   // life-time counters of the handle (RSREC_REPORT)
@@ -115,11 +116,13 @@ struct rsrec_handle {
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
+    long opt_s5_split = 0;       // persistent k_spmm5: 3 = a wave takes a third of a group's tiles (k_spmm5<., true, false, 3>; s5_waves = 8 / 12 / 16 waves per CU then)
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
     long opt_s5_spin_xcd = 0;    // persistent k_spmm5 on collinear operators: 1 = even XCDs serve output spin 0, odd XCDs spin 1; 0 = both spins on every XCD
     long opt_s5_octet = 64;      // atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS instead of one atom + 7 padding tiles (0: never)
     long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
+    long opt_kubo_vbatch = 0;    // rsrec_kubo_moments: random vectors advanced together as the chains of one launch (0: up to 8, as many as fit beside a whole left matrix)
     int n_kubo_left_chunks = 0;
     long opt_orth3 = 1;          // k_mfma_orth3: 1 one 512-register wave per SIMD (tables in registers), 2 two waves per SIMD (tables in LDS)
     long opt_graph = 1;          // level loop of small batches as one HIP graph: 0 never, 1 calls of up to 8 chains, 2 every single-batch call
@@ -429,7 +432,9 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "graph")) h->opt_graph = value;
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
+    else if (!strcmp(key, "s5_split")) h->opt_s5_split = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
+    else if (!strcmp(key, "kubo_vbatch")) h->opt_kubo_vbatch = value;
     else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
     else if (!strcmp(key, "s5_octet")) h->opt_s5_octet = value;
     else if (!strcmp(key, "s5_spin_xcd")) h->opt_s5_spin_xcd = value;
@@ -1044,7 +1049,9 @@ void s5_prepare(rsrec_t* h) {
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, h->device) == hipSuccess && optin > 64 * 1024) {
         const int ask = (int)std::min<size_t>((size_t)optin, S5_LDS_LIMIT);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<false, true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmm5<true, true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
             h->s5_lds_limit = (size_t)ask;
     }
     (void)hipGetLastError();
@@ -1079,6 +1086,10 @@ void launch_s5_one(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, 
         // s5_waves = 4 (persistent form only): half-size workgroups, one wave per SIMD -- the other half of every CU's registers stays free
         // for the kernels of another stream (the HBM-bound post-hop passes of the other half batch)
         const unsigned thr = (queue && h->opt_s5_waves == 4) ? S5_WG_GROUPS * 64 : S5_WG_GROUPS * 128;
+        if (queue && h->opt_s5_split == 3) {
+            const unsigned thr3 = 64u * (unsigned)std::min<long>(16, std::max<long>(8, h->opt_s5_waves));
+            k_spmm5<TWO, true, false, 3><<<g2, thr3, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
+        } else
         k_spmm5<TWO, true><<<g2, thr, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
         k_spmm5<TWO, false><<<grid, S5_WG_GROUPS * 128, 0, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, extra, ntau, 0, nullptr, 1, epi);
@@ -1442,7 +1453,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
                                           (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet, (uintptr_t)h->opt_s5_spin_xcd,
                                           (uintptr_t)h->lattice_epoch, (uintptr_t)OP.sched_epoch, (uintptr_t)h->nslots, (uintptr_t)h->nmax, (uintptr_t)h->ntype, (uintptr_t)h->hslots,
-                                          (uintptr_t)h->opt_s5_waves, (uintptr_t)h->opt_batch, (uintptr_t)B, (uintptr_t)h->opt_kernels, (uintptr_t)h->n_cu};
+                                          (uintptr_t)h->opt_s5_waves, (uintptr_t)h->opt_s5_split, (uintptr_t)h->opt_batch, (uintptr_t)B, (uintptr_t)h->opt_kernels, (uintptr_t)h->n_cu};
             for (int v = 0; v < nvec; ++v) key.push_back((uintptr_t)h->d_vec[v].p);
             if (!h->graph_exec || key != h->graph_key) {
                 if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -2347,7 +2358,8 @@ void kubo_spmm(const KuboCtx& K, const Spmm5Operator& op, int set, const double*
         double f = -1.0;                                  // required flops of (op, set): computed once per call
         for (auto& e : *K.req) if (std::get<0>(e) == &op && std::get<1>(e) == set) f = std::get<2>(e);
         if (f < 0.0) { f = kubo_required_flops(h, op, set); K.req->emplace_back(&op, set, f); }
-        h->n_req_flop += f;
+        h->n_req_flop += f * K.SD.nchains;
+        h->n_kubo_chain_launches += K.SD.nchains;
     }
 }
 // out = H in   (ham_vec_matmul :913 / ham_hoh_vec_matmul :785 before their scale-and-shift), or with an epilogue the whole Chebyshev
@@ -2414,30 +2426,37 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         return (int)std::max<long>(8, (ksp + 7) / 8 * 8);
     };
     auto part_bytes = [&](int lc) { return (double)ksplit_for(lc) * ((lc * NB + KG_BLK - 1) / KG_BLK) * KG_BLK * (double)nbn_max * KG_BLK * 16.0; };
-    auto need_for = [&](int lc) { return (11.0 + lc + nchunk) * velems * 8 + part_bytes(lc) + (double)cond_ll * cond_ll * BLK * 16.0; };
+    // Vectors in flight: the vectors of a call are independent (recursion.f90:1104: one pass of the loop each) and one whole-lattice product is
+    // kk / 8 groups -- 1 000 on 8 000 atoms, half a round of the device's wave slots per spin.  Up to 8 of them advance together as the CHAINS of
+    // every launch (chain c of a buffer slot lies c vectors behind chain 0, exactly like the sites of a recursion batch); each keeps its own
+    // left / right matrices and is contracted by itself.  A whole left matrix per vector goes first: vectors are added only while it fits.
+    auto need_for = [&](int lc, int nv) { return (11.0 + lc + nchunk) * nv * velems * 8 + part_bytes(lc) + (double)nv * cond_ll * cond_ll * BLK * 16.0; };
     int lchunk = cond_ll;
     if (h->opt_kubo_lchunk > 0) lchunk = (int)std::min<long>(cond_ll, h->opt_kubo_lchunk);
-    while (lchunk > 1 && need_for(lchunk) > budget) lchunk = (lchunk + 1) / 2;
-    if (need_for(lchunk) > budget)
-        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for one left vector at a time on %d atoms, %.1f GB free", need_for(1) * 1e-9, kk, free_b * 1e-9);
+    int nbv = (int)std::min<long>(nvec, h->opt_kubo_vbatch > 0 ? h->opt_kubo_vbatch : 8);
+    while (nbv > 1 && need_for(lchunk, nbv) > budget) --nbv;
+    while (lchunk > 1 && need_for(lchunk, nbv) > budget) lchunk = (lchunk + 1) / 2;
+    if (need_for(lchunk, nbv) > budget)
+        return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for one left vector at a time on %d atoms, %.1f GB free", need_for(1, 1) * 1e-9, kk, free_b * 1e-9);
     for (int v = 0; v < 6; ++v) h->d_vec[v].release();
+    const size_t sstride = (size_t)nbv * velems;                                // doubles between two slots of a buffer (nbv chains each)
     DevBuf work, Lm, Rm, Part, Mu;
     auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Part.release(); Mu.release(); };
-    if (work.reserve(11 * velems * 8) != hipSuccess || Lm.reserve((size_t)lchunk * velems * 8) != hipSuccess || Rm.reserve((size_t)nchunk * velems * 8) != hipSuccess ||
-        Part.reserve((size_t)part_bytes(lchunk)) != hipSuccess || Mu.reserve((size_t)cond_ll * cond_ll * BLK * 16) != hipSuccess) {
+    if (work.reserve(11 * sstride * 8) != hipSuccess || Lm.reserve((size_t)lchunk * sstride * 8) != hipSuccess || Rm.reserve((size_t)nchunk * sstride * 8) != hipSuccess ||
+        Part.reserve((size_t)part_bytes(lchunk)) != hipSuccess || Mu.reserve((size_t)nbv * cond_ll * cond_ll * BLK * 16) != hipSuccess) {
         cleanup();
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: out of device memory");
     }
-    HIPCK(h, hipMemsetAsync(Lm.p, 0, (size_t)lchunk * velems * 8, h->stream));    // (block kk of every slot stays the zero block)
-    HIPCK(h, hipMemsetAsync(Rm.p, 0, (size_t)nchunk * velems * 8, h->stream));
-    HIPCK(h, hipMemsetAsync(work.p, 0, 11 * velems * 8, h->stream));            // block kk of every vector stays the zero block
+    HIPCK(h, hipMemsetAsync(Lm.p, 0, (size_t)lchunk * sstride * 8, h->stream));    // (block kk of every slot stays the zero block)
+    HIPCK(h, hipMemsetAsync(Rm.p, 0, (size_t)nchunk * sstride * 8, h->stream));
+    HIPCK(h, hipMemsetAsync(work.p, 0, 11 * sstride * 8, h->stream));            // block kk of every vector stays the zero block
     double* V[11];
-    for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * velems;
+    for (int v = 0; v < 11; ++v) V[v] = work.as<double>() + (size_t)v * sstride;
     double *psiref = V[0], *w0 = V[1], *w1 = V[2], *w2 = V[3];
     double *l0 = V[4], *l1 = V[9];                                              // T_{m0-2} r, T_{m0-1} r: the left recurrence across a chunk border
     HIPCK(h, h->d_seed.reserve((size_t)nseed * 4));
     HIPCK(h, h->d_seedcoef.reserve((size_t)nseed * sizeof(double2)));
-    // region list: all atoms (every launch of this path runs over the whole lattice)
+    // region list: all atoms (every launch of this path runs over the whole lattice), one row shared by the chains of a launch
     std::vector<int> all(kk);
     for (int i = 0; i < kk; ++i) all[i] = i;
     int ostride = kk;
@@ -2446,32 +2465,39 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     if (rc) { cleanup(); return rc; }
     KuboCtx K;
     K.h = h;
-    K.CV.order = h->cur_order; K.CV.cum = h->cur_cum; K.CV.obase = h->cur_cum + (size_t)h->cur_nrows * 1; K.CV.nlev = 1; K.CV.vstride = velems; K.CV.cpo = 1; K.CV.ostride = ostride;
-    K.SD = SpmmDims{kk, h->nslots, h->nmax, 1, 1, ostride, 0, velems, K.CV.obase, 1};
-    K.grid = s5_grid(h, dim3(256, 1), 0);
+    K.CV.order = h->cur_order; K.CV.cum = h->cur_cum; K.CV.obase = h->cur_cum + (size_t)h->cur_nrows * 1; K.CV.nlev = 1; K.CV.vstride = velems; K.CV.cpo = nbv; K.CV.ostride = ostride;
     K.iz = h->d_iz.as<int>();
     K.hps = V[6]; K.p1 = V[7]; K.p2 = V[8];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spmm_ev, gemm_ev;
     K.spmm_ev = &spmm_ev;
     std::vector<std::tuple<const Spmm5Operator*, int, double>> req_tab;
     K.req = &req_tab;
+    h->n_kubo_chain_launches = 0;
     hipEvent_t e_begin = next_event(h);
     int n_left_chunks = 0;
-    auto Lslot = [&](int q) { return Lm.as<double>() + (size_t)q * velems; };
-    auto Rslot = [&](int q) { return Rm.as<double>() + (size_t)q * velems; };
-    for (int iv = 0; iv < nvec; ++iv) {
+    auto Lslot = [&](int q) { return Lm.as<double>() + (size_t)q * sstride; };
+    auto Rslot = [&](int q) { return Rm.as<double>() + (size_t)q * sstride; };
+    for (int iv0 = 0; iv0 < nvec; iv0 += nbv) {
+        const int nb = std::min(nbv, nvec - iv0);                                 // vectors of this batch = chains of its launches
+        K.SD = SpmmDims{kk, h->nslots, h->nmax, 1, nbv, ostride, 0, velems, K.CV.obase, nb};
+        K.grid = s5_grid(h, dim3(256, (unsigned)nb), 0);
         // r_i: psiref(l,l,seed(k)) = coef(k); seed atom 0 = unused entry
-        std::vector<int> s0; std::vector<double> c0;
-        for (int k = 0; k < nseed; ++k) {
-            const int at = seed_atoms[(size_t)iv * nseed + k];
-            if (at == 0) continue;
-            s0.push_back(at - 1); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k)]); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k) + 1]);
+        HIPCK(h, hipMemsetAsync(psiref, 0, sstride * 8, h->stream));
+        for (int c = 0; c < nb; ++c) {
+            const int iv = iv0 + c;
+            std::vector<int> s0; std::vector<double> c0;
+            for (int k = 0; k < nseed; ++k) {
+                const int at = seed_atoms[(size_t)iv * nseed + k];
+                if (at == 0) continue;
+                s0.push_back(at - 1); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k)]); c0.push_back(seed_coef[2 * ((size_t)iv * nseed + k) + 1]);
+            }
+            if (s0.empty()) { cleanup(); return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: vector %d has no seed", iv + 1); }
+            XFER(xfer_h2d(h, h->d_seed.p, s0.data(), s0.size() * 4));
+            XFER(xfer_h2d(h, h->d_seedcoef.p, c0.data(), c0.size() * 8));
+            k_seed<LayoutCI><<<1, 64, 0, h->stream>>>(psiref + (size_t)c * velems, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), (int)s0.size());
+            HIPCK(h, hipStreamSynchronize(h->stream));                            // the seed tables are reused by the next vector
         }
-        if (s0.empty()) { cleanup(); return fail(h, RSREC_ERR_ARG, "rsrec_kubo_moments: vector %d has no seed", iv + 1); }
-        XFER(xfer_h2d(h, h->d_seed.p, s0.data(), s0.size() * 4));
-        XFER(xfer_h2d(h, h->d_seedcoef.p, c0.data(), c0.size() * 8));
-        HIPCK(h, hipMemsetAsync(psiref, 0, nd * 8, h->stream));
-        k_seed<LayoutCI><<<1, 64, 0, h->stream>>>(psiref, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), (int)s0.size());
+        const size_t cpy = ((size_t)(nb - 1) * velems + nd) * 8;                  // the chains of a slot, up to the last one's zero block
         for (int m0 = 0; m0 < cond_ll; m0 += lchunk) {
             const int ml = std::min(lchunk, cond_ll - m0), m_rows = ml * NB;
             ++n_left_chunks;
@@ -2481,14 +2507,14 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
                 double* out = Lslot(m - m0);
                 const double* prev1 = m - 1 >= m0 ? Lslot(m - 1 - m0) : l1;
                 const double* prev2 = m - 2 >= m0 ? Lslot(m - 2 - m0) : (m - 2 == m0 - 1 ? l1 : l0);
-                if (m == 0) HIPCK(h, hipMemcpyAsync(out, psiref, nd * 8, hipMemcpyDeviceToDevice, h->stream));
+                if (m == 0) HIPCK(h, hipMemcpyAsync(out, psiref, cpy, hipMemcpyDeviceToDevice, h->stream));
                 else if (m == 1) kubo_apply_h(K, prev1, out, cheb_epilogue(true, prev1, nullptr, a, b));
                 else kubo_apply_h(K, prev1, out, cheb_epilogue(false, prev1, prev2, a, b));
             }
             if (m0 + ml < cond_ll) {                                          // state for the next chunk (its slots are about to be reused)
-                if (ml >= 2) HIPCK(h, hipMemcpyAsync(l0, Lslot(ml - 2), nd * 8, hipMemcpyDeviceToDevice, h->stream));
-                else HIPCK(h, hipMemcpyAsync(l0, l1, nd * 8, hipMemcpyDeviceToDevice, h->stream));
-                HIPCK(h, hipMemcpyAsync(l1, Lslot(ml - 1), nd * 8, hipMemcpyDeviceToDevice, h->stream));
+                if (ml >= 2) HIPCK(h, hipMemcpyAsync(l0, Lslot(ml - 2), cpy, hipMemcpyDeviceToDevice, h->stream));
+                else HIPCK(h, hipMemcpyAsync(l0, l1, cpy, hipMemcpyDeviceToDevice, h->stream));
+                HIPCK(h, hipMemcpyAsync(l1, Lslot(ml - 1), cpy, hipMemcpyDeviceToDevice, h->stream));
             }
             // right vectors  v_a T_{n-1}(H~) v_b r  (:1154-1187), written into the slots of Rm and contracted with the left vectors of
             // this chunk, 64 at a time
@@ -2524,14 +2550,17 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
                     HIPCK(h, hipGetLastError());
                     hipEvent_t g0 = next_event(h);
                     const unsigned wgs = 8u * (unsigned)(((long)nbm * nbn * (ksplit / 8) + 3) / 4);
-                    k_kubo_gram<<<wgs, 256, 0, h->stream>>>(Lm.as<double>(), velems, m_rows, Rm.as<double>(), velems, ncols, ksteps_total, ksplit, Part.as<double2>(), nbm, nbn);
-                    k_kubo_gram_reduce<<<std::min(4096, (m_rows * ncols + 255) / 256), 256, 0, h->stream>>>(Part.as<double2>(), ksplit, nbm * bmr, nbn * bnc, m_rows, ncols, Mu.as<double2>(), cond_ll, m0, n0);
+                    // one contraction per vector of the batch: its matrices are the chain-c columns of the slots (leading dimension = a whole slot)
+                    for (int c = 0; c < nb; ++c) {
+                        k_kubo_gram<<<wgs, 256, 0, h->stream>>>(Lm.as<double>() + (size_t)c * velems, sstride, m_rows, Rm.as<double>() + (size_t)c * velems, sstride, ncols, ksteps_total, ksplit, Part.as<double2>(), nbm, nbn);
+                        k_kubo_gram_reduce<<<std::min(4096, (m_rows * ncols + 255) / 256), 256, 0, h->stream>>>(Part.as<double2>(), ksplit, nbm * bmr, nbn * bnc, m_rows, ncols, Mu.as<double2>() + (size_t)c * cond_ll * cond_ll * BLK, cond_ll, m0, n0);
+                    }
                     gemm_ev.emplace_back(g0, next_event(h));
                 }
             }
         }
         HIPCK(h, hipGetLastError());
-        XFER(xfer_d2h(h, mu_nm + 2 * (size_t)BLK * cond_ll * cond_ll * iv, Mu.p, (size_t)cond_ll * cond_ll * BLK * 16));
+        XFER(xfer_d2h(h, mu_nm + 2 * (size_t)BLK * cond_ll * cond_ll * iv0, Mu.p, (size_t)nb * cond_ll * cond_ll * BLK * 16));
     }
     hipEvent_t e_end = next_event(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -2546,8 +2575,8 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         double fan = 0.0;
         for (int i = 0; i < kk; ++i)
             for (int s2 = 0; s2 < h->nslots; ++s2) if (h->nbr[(size_t)i * h->nslots + s2] >= 0) fan += 1.0;
-        h->n_block_mult = fan * (double)spmm_ev.size();
-        h->n_atom_steps = (double)kk * (double)spmm_ev.size();
+        h->n_block_mult = fan * h->n_kubo_chain_launches;
+        h->n_atom_steps = (double)kk * h->n_kubo_chain_launches;
     }
     cleanup();
     return RSREC_OK;

@@ -154,3 +154,29 @@ def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, colli
     assert div == 0
     assert rel_err(rec.mu_n, mu_o) < RTOL
     rec.close()
+
+
+@pytest.mark.parametrize("waves", [8, 12])
+@pytest.mark.parametrize("kk,nslots,hoh,collinear", [(180, 15, False, True), (180, 15, True, True), (150, 31, True, False), (97, 1, False, False), (233, 30, False, False)])
+def test_split_tasks_equal_the_nine_tile_wave_bitwise(kk, nslots, hoh, collinear, waves):
+    """Option s5_split = 3 (k_spmm5<., true, false, 3>: a wave takes a third of a group's nine tiles; persistent form of one-class operators)
+    accumulates every tile in the same k order as the nine-tile wave: block Lanczos and Chebyshev results must be bitwise the same, on
+    ragged lattices (padding atoms in the last group, absent neighbours), with and without hoh (two-input second pass) and with
+    spin-mixing blocks."""
+    rng = np.random.default_rng(4242 + kk + nslots + int(hoh))
+    p = random_problem(rng, kk, nslots, 1, 0, hoh, collinear)
+    irec = np.array([1, kk // 2, kk], np.int32)
+    rec = Recursion(*objects_from(p, irec, 6, emin=-60.0, emax=60.0), device=0)
+    for k, v in (("kernels", 2), ("spmm5", 2), ("s5_queue", 2), ("graph", 0)):
+        rec.set_option(k, v)
+    rec.recur_b()
+    a0, b0 = rec.a_b.copy(), rec.b2_b.copy()
+    rec.chebyshev_recur()
+    m0 = rec.mu_n.copy()
+    rec.set_option("s5_split", 3)
+    rec.set_option("s5_waves", waves)
+    rec.recur_b()
+    assert np.isfinite(rec.a_b).all() and np.array_equal(rec.a_b, a0) and np.array_equal(rec.b2_b, b0)
+    rec.chebyshev_recur()
+    assert np.array_equal(rec.mu_n, m0)
+    rec.close()

@@ -37,11 +37,12 @@ def run(p, seeds, coefs, lld, nch, label):
 
 if __name__ == "__main__":
     lld, nch = 12, 64
-    p = supercell_problem((22, 22, 22))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+    p = supercell_problem((n, n, n))
     kk = p["nn"].shape[0]
     seeds = np.arange(1, kk + 1, 8, dtype=np.int32)          # one seed per group of 8 consecutive atoms
     coefs = np.full(len(seeds), 1.0 / np.sqrt(len(seeds)), dtype=np.complex128)
-    run(p, seeds, coefs, lld, nch, "bcc 22^3 (real gathers)")
+    run(p, seeds, coefs, lld, nch, "bcc %d^3 (real gathers)" % n)
     q = dict(p)
     nn = p["nn"].copy()
     base = (np.arange(kk) // 8) * 8
