@@ -13,7 +13,7 @@ FC="${FC:-/opt/rocm/bin/amdflang}"
 MKLDIR="${MKLDIR:-/opt/conda/lib}"
 if [ ! -f "$OUT/librslmto_ref.a" ]; then echo "oracle/_ref not built: skipping Fortran drop-in build"; exit 0; fi
 FFLAGS="-cpp -O2 -fopenmp -J$OUT/mod -I$OUT/mod"
-for f in rsrec_binding rsrec_context recursion_gpu green_gpu bands_gpu hamiltonian_gpu lattice_cells; do
+for f in rsrec_binding rsrec_context recursion_gpu dos_gpu green_gpu bands_gpu hamiltonian_gpu lattice_cells; do
   (cd "$OUT/obj" && "$FC" $FFLAGS -c "$HERE/$f.f90" -o "$OUT/obj/$f.o")
 done
 # the test programs (tests/fortran/): the reference's workflows with the drop-in types behind them

@@ -2,7 +2,7 @@
 # ZERO-EDIT DROP-IN BUILD: the reference program linked from its own UNMODIFIED sources (main.f90, calculation.f90, self.f90 and every
 # other file, compiled where they lie under /root/reference/source) with the GPU types behind the reference's module names.
 #
-# How: the five reference files whose types have a GPU counterpart are compiled under another module name
+# How: the six reference files whose types have a GPU counterpart are compiled under another module name
 # (-D<name>_mod=<name>_ref_mod; the reference's sources are compiled with -cpp anyway, CMakeLists.txt), the GPU type of fortran/
 # extends the reference type from there (same -D, so its `use <name>_mod` finds the renamed reference module), and
 # fortran/shadow/<name>_mod.f90 re-exports the extended type under the reference's names.  Everything downstream -- `type(recursion) ::
@@ -48,7 +48,7 @@ fc "$HERE/rsrec_binding.f90" rsrec_binding
 fc "$HERE/rsrec_context.f90" rsrec_context
 shadowed hamiltonian hamiltonian_gpu
 shadowed recursion recursion_gpu
-ref density_of_states.f90
+shadowed density_of_states dos_gpu
 shadowed green green_gpu
 shadowed bands bands_gpu
 ref xc.f90 mix.f90 self.f90 exchange.f90 conductivity.f90 include_codes/abspinlib/stdtypes.f90 include_codes/abspinlib/mtprng.f90 include_codes/abspinlib/parameters.f90 include_codes/abspinlib/constants.f90 include_codes/abspinlib/randomnumbers.f90 include_codes/abspinlib/depondt.f90 spin_dynamics.f90 calculation.f90 include_codes/abspinlib/abSpinlib.f90 include_codes/abspinlib/constrain.f90

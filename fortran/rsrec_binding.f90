@@ -132,6 +132,14 @@ module rsrec_binding
          integer(c_int) :: rc
       end function
 
+      function rsrec_scalar_density(handle, nsites, nmdir, llmax, lld, a, b2, npts, ene, dw_l, cshi, tdens) bind(C, name='rsrec_scalar_density') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: handle
+         integer(c_int), value :: nsites, nmdir, llmax, lld, npts
+         type(c_ptr), value :: a, b2, ene, dw_l, cshi, tdens
+         integer(c_int) :: rc
+      end function
+
       function rsrec_block_ldos(handle, nen, ene, eta_re, eta_im, sym_term, site_offset, nsites_total, dtot, dosia, dosial, a_inf, b_inf) &
          bind(C, name='rsrec_block_ldos') result(rc)
          import :: c_int, c_ptr, c_double

@@ -144,6 +144,17 @@ int rsrec_block_green(rsrec_t *h, int nsites, int lld, int nen, const double *en
 int rsrec_terminator(rsrec_t *h, int nsites, int lld, const double *a_b, const double *b_sqrt, double *a_inf, double *b_inf,
                      double *a_inf0, double *b_inf0);
 
+/* The stage behind the SCALAR recursion (control%recur = 'lanczos'): replaces dos%density (density_of_states.f90:248-363) with its
+ * continued fraction bprldos (:370-404), which green%sgreen (green.f90:628-705) calls for every site and direction and turns into g0.
+ * Per chain (orbital, site, direction): the Beer-Pettifor band edges (bpOPT on sqrt(b2), recursion.f90:3540; x 1.01 on orbitals 1 and 10),
+ * then one scalar continued fraction per energy, closed by the square-root terminator of that band -- one GPU thread each, the reference's
+ * operations in the reference's order.
+ *   a, b2  : real (llmax,18,nsites,nmdir) = recursion%a, %b2 (recursion.f90:3485 recur);  lld = control%lld <= llmax
+ *   ene    : real (npts) = energy%ene(1:channels_ldos+10);  dw_l, cshi : real (18,nsites) = potential%dw_l, %cshi of the sites' atoms
+ *   tdens  : real (18,npts,nsites,nmdir) out = density's `tdens` for every (site, direction) */
+int rsrec_scalar_density(rsrec_t *h, int nsites, int nmdir, int llmax, int lld, const double *a, const double *b2, int npts, const double *ene,
+                         const double *dw_l, const double *cshi, double *tdens);
+
 /* The whole LDOS stage for the sites of the LAST rsrec_block_lanczos call, from the coefficients that call left on the device
  * (nothing is uploaded but the energy mesh): zsqr (recursion.f90:1980) -> get_terminf (:2092) -> green%bgreen (green.f90:1191,
  * eta / sym_term as in rsrec_block_green) -> the reduction of bands%calculate_fermi (bands.f90:258-268),
@@ -264,14 +275,16 @@ int rsrec_comm_destroy(rsrec_t *h);
  *   "s5_lds"     k_spmm5 with the operator fragments in LDS: 0 = never, 1 = operators with one class of atoms, whenever their stream fits,
  *                2 = also operators with several classes (one run of groups per class of the class-sorted atom list; slower) [1]
  *   "s5_queue"   the LDS form as persistent workgroups (one per CU) with per-(chain, XCD) group counters: 0 = never, 1 = launches of >= 256
- *                workgroups, 2 = always [1];  "s5_waves" waves per persistent workgroup, 8 or 4 [8];  "s5_run_min" smallest class run
+ *                workgroups, 2 = always [1];  "s5_waves" waves per persistent workgroup, 8 or 4 [8];  "s5_split" 3 = a wave of the persistent form takes a
+ *                third of a group's nine tiles (bitwise the same results, measured slower: DESIGN.md; s5_waves 8 / 12 then) [0];  "s5_run_min" smallest class run
  *                (groups) that gets LDS workgroups of its own under s5_lds = 2 [0 = by launch size]
  *   "s5_spin_xcd" persistent form on collinear operators: 1 = even XCDs serve output spin 0 and odd XCDs spin 1 (an XCD's L2 then holds one
  *                spin half of the neighbour blocks; the round-2 default), 0 = both spins on every XCD (2-4 % faster, round 3) [0]
  *   "s5_octet"   atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS of the batch (they then share
- *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [64]
+ *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [8]
  *   "s5_host_emit" 1 = swizzle k_spmm5's operator streams on the host instead of assembling them on the device (cross-check) [0]
- *   "kubo_lchunk" rsrec_kubo_moments: left vectors held on the device at a time [0 = as many as fit] */
+ *   "kubo_lchunk" rsrec_kubo_moments: left vectors held on the device at a time [0 = as many as fit];  "kubo_vbatch" vectors of a call advanced
+ *                together as the chains of every launch [0 = up to 8, as many as fit beside a whole left matrix each] */
 int rsrec_set_option(rsrec_t *h, const char *key, long value);
 /* Timing of the last recursion call, measured with HIP events on the engine's own stream:
  *   out[0] total device ms, out[1] ms in the H|psi> kernels, out[2] number of H|psi> launches,

@@ -47,6 +47,7 @@ program dump_fixture
    integer, parameter :: neta = 5
    complex(rp) :: eta_c
    complex(rp), allocatable :: g_ef(:, :, :)
+   real(rp), allocatable :: doso(:, :)
    integer :: ia, u, kind_rec, nslots, hoh_i, nsites, ncheb
    real(rp) :: acheb, bcheb
    character(len=32) :: pre, envbuf
@@ -208,6 +209,32 @@ program dump_fixture
    case (2)
       write (u) recursion_obj%a(:, :, :, 1)
       write (u) recursion_obj%b2(:, :, :, 1)
+      ! ---- the stage right after the scalar recursion (self.f90:822-823, run_dos): green%sgreen (green.f90:628-705), which calls
+      !      dos%density (density_of_states.f90:248-363: bpOPT band edges + one scalar continued fraction bprldos :370-404 per
+      !      orbital and energy).  Appended so that the device version of that stage can be pinned: energies, the potential
+      !      parameters density reads, its output for every (site, direction), and the g0 sgreen makes of it.
+      dos_obj = dos(recursion_obj, energy_obj)
+      green_obj = green(dos_obj)
+      call energy_obj%e_mesh()
+      nen = energy_obj%channels_ldos + 10
+      write (u) int(z'44454e31'), nen, control_obj%nmdir
+      write (u) energy_obj%ene(1:nen)
+      do ia = 1, lattice_obj%nrec
+         write (u) lattice_obj%symbolic_atoms(l2g_map(ia))%potential%dw_l(1:18)
+         write (u) lattice_obj%symbolic_atoms(l2g_map(ia))%potential%cshi(1:18)
+      end do
+      write (u) recursion_obj%a(:, :, 1:lattice_obj%nrec, 1:control_obj%nmdir)
+      write (u) recursion_obj%b2(:, :, 1:lattice_obj%nrec, 1:control_obj%nmdir)
+      allocate (doso(18, nen))
+      do sym_i = 1, control_obj%nmdir
+         do ia = 1, lattice_obj%nrec
+            doso = 0.0_rp
+            call dos_obj%density(doso, ia, sym_i)
+            write (u) doso
+         end do
+      end do
+      call green_obj%sgreen()
+      write (u) green_obj%g0(:, :, 1:nen, 1:lattice_obj%nrec)
    end select
    close (u)
    ! ---- local_axis = T (recursion.f90:1830-1832): the chain of site i ran on the blocks rotated into the spin frame of that

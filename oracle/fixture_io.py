@@ -18,6 +18,7 @@ MAGIC = 0x52534658
 GREEN_MAGIC = 0x47524e31
 ETA_GREEN_MAGIC = 0x47524e33
 CHEB_GREEN_MAGIC = 0x47524e32
+DENSITY_MAGIC = 0x44454e31
 KIND_BLOCK, KIND_CHEB, KIND_SCALAR, KIND_BLOCK_IJ, KIND_CHEB_IJ = 0, 1, 2, 3, 4
 
 
@@ -57,6 +58,18 @@ def read_fixture_bin(path):
             # Green-function stage appended by dump_fixture.f90 for block recursions (self.f90:820-831 run_dos):
             # energies, terminator, sqrt(B^2) (zsqr), g0 = block_green (green.f90:588-621, bgreen :1191-1339)
             gmagic, nen, sym = struct.unpack("<iii", tail)
+            if gmagic == DENSITY_MAGIC:        # scalar recursion: green%sgreen / dos%density (green.f90:628-705, density_of_states.f90:248-404); sym = nmdir
+                nmd = sym
+                dn = dict(nen=nen, nmdir=nmd, ene=_rd(f, np.float64, (nen,)))
+                pot = _rd(f, np.float64, (18, 2, nrec))                  # per site: dw_l(1:18), cshi(1:18)
+                dn["dw_l"], dn["cshi"] = np.asfortranarray(pot[:, 0, :]), np.asfortranarray(pot[:, 1, :])
+                dn["a"] = _rd(f, np.float64, (llmax, 18, nrec, nmd))
+                dn["b2"] = _rd(f, np.float64, (llmax, 18, nrec, nmd))
+                dn["tdens"] = _rd(f, np.float64, (18, nen, nrec, nmd))   # written (site fastest, then direction): same order
+                dn["g0"] = _rd(f, np.complex128, (18, 18, nen, nrec))
+                d["density"] = dn
+                assert f.read(1) == b"", "trailing bytes in fixture"
+                return d
             if gmagic == CHEB_GREEN_MAGIC:     # chebyshev_green (green.f90:1030-1108): energies, g0
                 d["green"] = dict(nen=nen, ene=_rd(f, np.float64, (nen,)), g0=_rd(f, np.complex128, (18, 18, nen, nrec)))
                 assert f.read(1) == b"", "trailing bytes in fixture"
@@ -131,7 +144,7 @@ OUTPUT_KEYS = ("a_b", "b2_b", "mu_n", "a", "b2")
 
 
 def save_golden(path, d, extra=None, drop=("cr",)):
-    out = {k: np.asarray(v) for k, v in d.items() if k not in drop and k != "nncols" and k != "llmax" and k != "green"}
+    out = {k: np.asarray(v) for k, v in d.items() if k not in drop and k != "nncols" and k != "llmax" and k != "green" and k != "density"}
     if not d.get("hoh"):
         # eeo/enim are not read by the non-hoh path: do not store megabytes of unused blocks
         out.pop("eeo", None); out.pop("enim", None); out.pop("hallo", None)

@@ -154,6 +154,41 @@ def run_case(name):
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+DENSITY_CASES = ["bccFe_nsp1_lanczos", "fccCu001_nsp1_lanczos", "B2FeCo_nsp1_lanczos"]
+DENSITY_STRIDE = 25        # every 25th energy of the reference's mesh is kept
+
+
+def run_density_case(name):
+    """<name>_density.npz: inputs and the reference's outputs of the stage behind the scalar recursion of the same run as <name>.npz --
+    dos%density (density_of_states.f90:248-363, bprldos :370-404) for every (site, direction) and the g0 green%sgreen makes of it
+    (green.f90:628-705) -- on a sub-sampled set of energies (every energy is an independent continued fraction)."""
+    case_dir, patch = CASES[name]
+    scratch = tempfile.mkdtemp(prefix="rsrec_dn_%s_" % name)
+    try:
+        for fn in os.listdir(os.path.join(REF, case_dir)):
+            if fn.endswith(".nml"):
+                shutil.copy(os.path.join(REF, case_dir, fn), os.path.join(scratch, fn))
+                os.chmod(os.path.join(scratch, fn), 0o644)
+        p = os.path.join(scratch, "input.nml")
+        txt = patch_namelist(open(p).read(), patch)
+        open(p, "w").write(txt)
+        r = run_ref(os.path.join(HERE, "_ref", "dump_fixture.x"), scratch)
+        if r.returncode != 0:
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            raise RuntimeError("dump_fixture failed for " + name)
+        d = fio.read_fixture_bin(os.path.join(scratch, "fixture.bin"))
+        g = d["density"]
+        idx = np.arange(0, g["nen"], DENSITY_STRIDE, dtype=np.int32)
+        out = dict(lld=d["lld"], llmax=d["llmax"], nrec=d["nrec"], nmdir=g["nmdir"], nen_full=g["nen"], ene_idx=idx, ene=g["ene"][idx],
+                   dw_l=g["dw_l"], cshi=g["cshi"], a=g["a"], b2=g["b2"], tdens=g["tdens"][:, idx], g0=g["g0"][:, :, idx, :],
+                   source_case=np.array(case_dir), namelist_patch=np.array(repr(patch)))
+        path = os.path.join(GOLD, name + "_density.npz")
+        np.savez_compressed(path, **out)
+        print("%-24s density: nen=%d kept=%d nrec=%d nmdir=%d llmax=%d -> %.1f KB" % (name, g["nen"], len(idx), d["nrec"], g["nmdir"], d["llmax"], os.path.getsize(path) / 1024))
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 GREEN_CASES = ["bccFe_nsp2_block", "bccFe_nsp4_block", "B2FeCo_block_hoh", "fccCu001_block_hoh", "bccFe_nsp2_cheb", "fccCu001_cheb"]
 GREEN_STRIDE = 40          # every 40th energy of the reference's mesh (channels_ldos + 10 points) is kept
 
@@ -639,7 +674,7 @@ def krylov_exhaustion_case(name="krylov_2x2x2", dims=(2, 2, 2), llds=range(6, 15
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + list(KUBO_CASES) + list(ORBITAL_CASES) + [c + "_hmag" for c in HMAG_CASES] + list(POSITION_CASES)
+    want = sys.argv[1:] or (list(CASES) + list(SUPERCELLS) + [c + "_green" for c in GREEN_CASES + list(GREEN_ONLY)] + [c + "_density" for c in DENSITY_CASES] + list(KUBO_CASES) + list(ORBITAL_CASES) + [c + "_hmag" for c in HMAG_CASES] + list(POSITION_CASES)
                             + ["sc_4x4x8_block_spread", "sc_4x4x8_block_hoh_spread"] + ["fuzz_seed_%d" % q for q in FUZZ_SEEDS] + ["krylov_2x2x2"])
     for n in want:
         if n == "krylov_2x2x2":
@@ -658,6 +693,8 @@ if __name__ == "__main__":
             spread_case(n[:-len("_spread")])
         elif n.endswith("_green"):
             run_green_case(n[:-len("_green")])
+        elif n.endswith("_density"):
+            run_density_case(n[:-len("_density")])
         elif n in CASES:
             run_case(n)
         else:

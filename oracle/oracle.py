@@ -201,6 +201,35 @@ def terminator(a_b, b_sqrt):
     return a_inf, b_inf, a0, b0
 
 
+def scalar_density(a, b2, ene, dw_l, cshi, lld=None):
+    """dos%density (density_of_states.f90:248-363; bprldos :370-404): a, b2 (llmax,18,nsites[,nmdir]) of the scalar recursion ->
+    tdens (18, len(ene), nsites, nmdir); dw_l, cshi (18, nsites)."""
+    a = np.asfortranarray(a, dtype=np.float64); b2 = np.asfortranarray(b2, dtype=np.float64)
+    if a.ndim == 3:
+        a = a[:, :, :, None]; b2 = b2[:, :, :, None]
+    a = np.asfortranarray(a); b2 = np.asfortranarray(b2)
+    llmax, _, n, nmd = a.shape
+    ene = np.ascontiguousarray(ene, dtype=np.float64)
+    dw_l = np.asfortranarray(dw_l, dtype=np.float64); cshi = np.asfortranarray(cshi, dtype=np.float64)
+    out = np.zeros((18, len(ene), n, nmd), order="F")
+    L = lib()
+    L.orc_scalar_density.restype = C.c_int
+    L.orc_scalar_density.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 4
+    rc = L.orc_scalar_density(n, nmd, llmax, int(lld or llmax), a.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), len(ene), ene.ctypes.data_as(C.c_void_p),
+                              dw_l.ctypes.data_as(C.c_void_p), cshi.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out
+
+
+def sgreen_from_density(tdens):
+    """green%sgreen for control%nmdir = 1 (green.f90:676-683): g0(j,j,ie,ia) = -i pi doso(j,ie); tdens (18, nen, nsites[, 1]) -> g0 (18,18,nen,nsites)."""
+    t = tdens[:, :, :, 0] if tdens.ndim == 4 else tdens
+    g0 = np.zeros((18, 18) + t.shape[1:], np.complex128, order="F")
+    for j in range(18):
+        g0[j, j] = -1j * t[j] * np.pi
+    return g0
+
+
 def chebyshev_green(mu_n, ene, emin, emax):
     """green%chebyshev_green (green.f90:1030) for ONE site: mu_n (18,18,2lld+2) -> g0 (18,18,len(ene))."""
     mu_n = np.asfortranarray(mu_n, dtype=np.complex128)

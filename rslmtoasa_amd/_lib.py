@@ -36,6 +36,7 @@ _SIGNATURES = {
     "rsrec_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rsrec_comm_destroy": (C.c_int, [C.c_void_p]),
     "rsrec_terminator": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "rsrec_scalar_density": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 4),
     "rsrec_block_ldos": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "rsrec_kubo_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 5),
     "rsrec_apply_operator": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]),

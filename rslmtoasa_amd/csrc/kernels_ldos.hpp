@@ -144,6 +144,84 @@ __global__ void k_terminator(int lld, const double2* __restrict__ a_b, const dou
     b_inf[(size_t)site * BLK + el] = rbinf;
 }
 
+// ---- the stage behind the SCALAR recursion: dos%density (density_of_states.f90:248-363) with bprldos (:370-404), which green%sgreen
+// (green.f90:628-705) turns into g0.  Chain c = (orbital nl, site ia, direction md) = nl + 18 (ia + nsites md); a, b2: [chain][llmax].
+//
+// k_scalar_edges: the Beer-Pettifor band of every chain -- bpOPT(lld, AA, sqrt(BB), lld - 1, ...) (:282), bm * 1.01 on orbitals 1 and 10
+// (:283), edge = am - 2 bm, width = 4 bm (:287-288) -> edges[2 c] = edge, edges[2 c + 1] = edge + width.  One thread per chain, the chain
+// staged in the thread's LDS column (as k_terminator); block = T threads, dynamic LDS = 2 * lld * T doubles.
+__global__ void k_scalar_edges(int lld, int llmax, int nchain, const double* __restrict__ a, const double* __restrict__ b2, double* __restrict__ edges) {
+#pragma clang fp contract(off)
+    extern __shared__ double chain_lds[];
+    const int T = blockDim.x, tid = threadIdx.x, c = blockIdx.x * T + tid;
+    if (c >= nchain) return;                                // (no barrier below: every thread reads only its own LDS column)
+    double* la = chain_lds + tid;
+    double* lb = chain_lds + (size_t)lld * T + tid;
+    for (int l = 0; l < lld; ++l) {
+        la[(size_t)l * T] = a[(size_t)c * llmax + l];
+        lb[(size_t)l * T] = sqrt(b2[(size_t)c * llmax + l]);
+    }
+    TermShifted S;
+    S.c.a = la; S.c.rb = lb; S.c.stride = T;
+    const int n = lld - 1;
+    S.n = n;
+    double ainf = S.c.A(n), bmax = 0.0, bmin = 0.0;
+    int jiter = 0;
+    for (;;) {                                              // bpopt :3557-3576
+        ++jiter;
+        S.ainf = ainf;
+        term_emami(S, bmax, bmin);
+        const double bm = fabs(bmax + bmin);
+        ainf = ainf + (bmax + bmin);
+        if (bm <= 1.0e-5) break;
+        else if (jiter > 300) break;
+    }
+    double bm1 = (bmax - bmin) / 2.0;
+    const int nl = c % NB;
+    if (nl == 0 || nl == 9) bm1 = 1.01 * bm1;
+    const double edge = ainf - 2.0 * bm1, width = 4.0 * bm1;
+    edges[2 * (size_t)c] = edge;
+    edges[2 * (size_t)c + 1] = edge + width;
+}
+
+// k_scalar_density: tdens(nl, ie, ia, md) = bprldos(ene(ie) / dw_l(nl, ia) - cshi(nl, ia), a, b2, lld, band) / dw_l(nl, ia)   (:331-341).
+// bprldos: Qt = (e - emid -+ sqrt((e - etop)(e - ebot))) / 2 on the branch with Im Qt <= 0, then Qt = B2(l) / (e - A(l) - Qt) for
+// l = lld - 1 .. 1, result -Im Qt / pi -- complex arithmetic spelled out the way the Fortran evaluates it (real operands promoted to (x, +0)).
+// grid = (ceil(npts / blockDim.x), nchain): one thread per (chain, energy); the chain is read through the cache by all threads of a block.
+__global__ void k_scalar_density(int lld, int llmax, int npts, int nsites, const double* __restrict__ a, const double* __restrict__ b2, const double* __restrict__ ene,
+                                 const double* __restrict__ dw_l, const double* __restrict__ cshi, const double* __restrict__ edges, double* __restrict__ tdens) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.y, ie = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ie >= npts) return;
+    const int nl = c % NB, ia = (c / NB) % nsites, md = c / (NB * nsites);
+    const double dw = dw_l[nl + NB * (size_t)ia], cs = cshi[nl + NB * (size_t)ia];
+    const double e = ene[ie] / dw - 1.00 * cs;
+    const double ebot = edges[2 * (size_t)c], etop = edges[2 * (size_t)c + 1];
+    const double emid_r = 0.5 * (etop + ebot), emid_i = 0.5 * (0.0 + 0.0);
+    const double ea_r = e - etop, ea_i = 0.0 - 0.0, eb_r = e - ebot, eb_i = 0.0 - 0.0;
+    const double det_r = ea_r * eb_r - ea_i * eb_i, det_i = ea_r * eb_i + ea_i * eb_r;
+    double z_r, z_i;                                         // principal square root (signed zero of the imaginary part decides the branch on the cut)
+    if (det_i == 0.0) {
+        if (det_r >= 0.0) { z_r = sqrt(det_r); z_i = det_i; }
+        else { z_r = 0.0; z_i = copysign(sqrt(-det_r), det_i); }
+    } else {
+        const double m = hypot(det_r, det_i);
+        z_r = sqrt(0.5 * (m + det_r));
+        z_i = copysign(sqrt(0.5 * (m - det_r)), det_i);
+    }
+    double q_r = ((e - emid_r) - z_r) * 0.5, q_i = ((0.0 - emid_i) - z_i) * 0.5;
+    if (q_i > 0.0) { q_r = ((e - emid_r) + z_r) * 0.5; q_i = ((0.0 - emid_i) + z_i) * 0.5; }
+    const double* aa = a + (size_t)c * llmax;
+    const double* bb = b2 + (size_t)c * llmax;
+    for (int l = lld - 1; l >= 1; --l) {
+        const double cr = (e - aa[l - 1]) - q_r, ci = 0.0 - q_i, den = cr * cr + ci * ci;
+        q_r = bb[l - 1] * cr / den;
+        q_i = -(bb[l - 1] * ci) / den;
+    }
+    const double dens = -q_i / 3.14159265358979323846;
+    tdens[nl + NB * ((size_t)ie + (size_t)npts * ((size_t)ia + (size_t)nsites * md))] = 0.0 + 1.0 * dens / dw;
+}
+
 // a_inf0(n) = mean diagonal of a_inf, b_inf0 likewise (after the 1.01 scaling), summed in index order (:2121-2131)
 __global__ void k_terminator_means(const double* __restrict__ a_inf, const double* __restrict__ b_inf, double* __restrict__ a_inf0, double* __restrict__ b_inf0, int nsites) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;

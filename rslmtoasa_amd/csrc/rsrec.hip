@@ -119,7 +119,7 @@ struct rsrec_handle {
     long opt_s5_split = 0;       // persistent k_spmm5: 3 = a wave takes a third of a group's tiles (k_spmm5<., true, false, 3>; s5_waves = 8 / 12 / 16 waves per CU then)
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
     long opt_s5_spin_xcd = 0;    // persistent k_spmm5 on collinear operators: 1 = even XCDs serve output spin 0, odd XCDs spin 1; 0 = both spins on every XCD
-    long opt_s5_octet = 64;      // atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS instead of one atom + 7 padding tiles (0: never)
+    long opt_s5_octet = 8;       // atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS instead of one atom + 7 padding tiles (0: never; round 3: 64; B2FeCo, nmax = 15: 2.38 -> 2.34 ms per launch)
     long opt_s5_host_emit = 0;   // 1: swizzle k_spmm5's operator streams on the host (round-2 path) instead of assembling them on the device
     long opt_kubo_lchunk = 0;    // rsrec_kubo_moments: left vectors held at a time (0: as many as fit)
     long opt_kubo_vbatch = 0;    // rsrec_kubo_moments: random vectors advanced together as the chains of one launch (0: up to 8, as many as fit beside a whole left matrix)
@@ -1975,6 +1975,48 @@ extern "C" int rsrec_terminator(rsrec_t* h, int nsites, int lld, const double* a
     XFER(xfer_d2h(h, b_inf, d_bi, tbytes));
     if (a_inf0) XFER(xfer_d2h(h, a_inf0, d_a0, (size_t)nsites * sizeof(double)));
     if (b_inf0) XFER(xfer_d2h(h, b_inf0, d_a0 + nsites, (size_t)nsites * sizeof(double)));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->t_total_ms = h->t_hop_ms = ev_ms(e0, e1);
+    return RSREC_OK;
+}
+
+// dos%density for every (site, direction) of a scalar-recursion run (density_of_states.f90:248-363, bprldos :370-404; called by
+// green%sgreen, green.f90:661): a, b2 (llmax, 18, nsites, nmdir) as recursion%a / %b2 hold them, dw_l, cshi (18, nsites) = the potential
+// parameters of the sites' atoms, ene (npts) -> tdens (18, npts, nsites, nmdir).
+extern "C" int rsrec_scalar_density(rsrec_t* h, int nsites, int nmdir, int llmax, int lld, const double* a, const double* b2, int npts, const double* ene,
+                                    const double* dw_l, const double* cshi, double* tdens) {
+    if (!h) return RSREC_ERR_ARG;
+    if (nsites < 0 || nmdir < 1 || lld < 2 || lld > llmax || npts < 0 || ((nsites > 0 && npts > 0) && (!a || !b2 || !ene || !dw_l || !cshi || !tdens)))
+        return fail(h, RSREC_ERR_ARG, "rsrec_scalar_density: bad argument");
+    if (nsites == 0 || npts == 0) return RSREC_OK;
+    HIPCK(h, hipSetDevice(h->device));
+    const int nchain = NB * nsites * nmdir;
+    const size_t cb = (size_t)nchain * llmax * sizeof(double), pb = (size_t)NB * nsites * sizeof(double), eb = (size_t)npts * sizeof(double),
+                 gb = 2 * (size_t)nchain * sizeof(double), tb = (size_t)nchain * npts * sizeof(double);
+    HIPCK(h, h->d_green_in.reserve(2 * cb + 2 * pb + eb + gb));
+    HIPCK(h, h->d_green_out.reserve(tb));
+    double* d_a = h->d_green_in.as<double>();
+    double* d_b = d_a + (size_t)nchain * llmax;
+    double* d_dw = d_b + (size_t)nchain * llmax;
+    double* d_cs = d_dw + (size_t)NB * nsites;
+    double* d_en = d_cs + (size_t)NB * nsites;
+    double* d_ed = d_en + npts;
+    double* d_t = h->d_green_out.as<double>();
+    XFER(xfer_h2d(h, d_a, a, cb));
+    XFER(xfer_h2d(h, d_b, b2, cb));
+    XFER(xfer_h2d(h, d_dw, dw_l, pb));
+    XFER(xfer_h2d(h, d_cs, cshi, pb));
+    XFER(xfer_h2d(h, d_en, ene, eb));
+    reset_timing(h);
+    hipEvent_t e0 = next_event(h);
+    const int T = 64;
+    const size_t lds = 2 * (size_t)lld * T * sizeof(double);
+    if (lds > 64 * 1024) return fail(h, RSREC_ERR_ARG, "rsrec_scalar_density: lld = %d too deep for the band-edge kernel", lld);
+    k_scalar_edges<<<(nchain + T - 1) / T, T, lds, h->stream>>>(lld, llmax, nchain, d_a, d_b, d_ed);
+    k_scalar_density<<<dim3((npts + 127) / 128, nchain), 128, 0, h->stream>>>(lld, llmax, npts, nsites, d_a, d_b, d_en, d_dw, d_cs, d_ed, d_t);
+    HIPCK(h, hipGetLastError());
+    hipEvent_t e1 = next_event(h);
+    XFER(xfer_d2h(h, tdens, d_t, tb));
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->t_total_ms = h->t_hop_ms = ev_ms(e0, e1);
     return RSREC_OK;

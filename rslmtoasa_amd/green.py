@@ -41,6 +41,35 @@ class Green:
                                             int(self.sym_term), _ptr(a_inf), _ptr(b_inf), _ptr(a_b), _ptr(b_s), _ptr(g0)))
         return g0
 
+    def density(self, dw_l=None, cshi=None, nsites=None, nmdir=1):
+        """dos%density for every site (and direction) of the last scalar recursion (density_of_states.f90:248-363, bprldos :370-404):
+        ``recursion.a, recursion.b2 (llmax,18,site[,mdir])`` -> ``tdens (18, nE, site, mdir)`` on the GPU.  ``dw_l, cshi (18, site)`` are the
+        potential parameters the reference reads (potential.f90:392-393: 1 and 0 unless set)."""
+        rec = self.recursion
+        a = np.asarray(rec.a); b2 = np.asarray(rec.b2)
+        if a.ndim == 3:
+            a = a[:, :, :, None]; b2 = b2[:, :, :, None]
+        n = a.shape[2] if nsites is None else nsites
+        a = np.asfortranarray(a[:, :, :n, :nmdir], dtype=np.float64); b2 = np.asfortranarray(b2[:, :, :n, :nmdir], dtype=np.float64)   # control%nmdir directions
+        llmax, nmd = a.shape[0], a.shape[3]
+        dw = np.ones((18, n), order="F") if dw_l is None else np.asfortranarray(dw_l, dtype=np.float64)
+        cs = np.zeros((18, n), order="F") if cshi is None else np.asfortranarray(cshi, dtype=np.float64)
+        assert dw.shape == (18, n) and cs.shape == (18, n)
+        tdens = np.zeros((18, len(self.ene), n, nmd), order="F")
+        rec._check(rec._L.rsrec_scalar_density(rec._h, n, nmd, llmax, int(rec.control.lld), _ptr(a), _ptr(b2), len(self.ene), _ptr(self.ene), _ptr(dw), _ptr(cs), _ptr(tdens)))
+        self.tdens = tdens
+        return tdens
+
+    def sgreen(self, dw_l=None, cshi=None, nsites=None):
+        """green%sgreen (green.f90:628-705) for control%nmdir = 1: g0(j,j,ie,ia) = -i pi doso(j,ie) with doso = dos%density on the GPU."""
+        t = self.density(dw_l, cshi, nsites)
+        assert t.shape[3] == 1, "sgreen: the nmdir = 3 combination (green.f90:684-699) stays the reference's host loop over density's output"
+        g0 = self._g0_buffer(t.shape[2])
+        g0[...] = 0.0
+        for j in range(18):
+            g0[j, j] = -1j * t[j, :, :, 0] * np.pi
+        return g0
+
     def terminator(self, nsites=None):
         """recursion%get_terminf (recursion.f90:2092) on the GPU for the coefficients held by the recursion object (b2_b after zsqr):
         returns a_inf, b_inf (18,18,n) and the mean diagonals a_inf0, b_inf0 (n)."""

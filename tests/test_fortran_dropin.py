@@ -86,6 +86,9 @@ def test_scf_workflow_with_gpu_recursion(name, build, tmp_path):
         n_dev = int(re.search(r"operator_arrays_from_device=(\d+)", log).group(1))
         hoh, imp = ".true." in str(case["patch"].get("hamiltonian", {}).get("hoh", "")), "impurity" in case["inputs"]
         assert n_asm >= 1 and n_dev == (2 if hoh else 1) * (2 if imp else 1), (n_asm, n_dev, log[-1500:])
+    if name == "Regression_bccFe_lanczos" and build == "dropin":
+        # scalar recursion: green%sgreen took dos%density from the device (fortran/dos_gpu.f90 behind the reference's density_of_states_mod)
+        assert "density-gpu" in log, log[-3000:]
     if "'chebyshev'" in str(case["patch"]) and "exe" not in case:
         assert "chebyshev-green-gpu" in log, log[-3000:]
     at, rt = case["abs_tol"], case["rel_tol"]

@@ -157,7 +157,7 @@ def test_recursions_on_random_ragged_lattice(kk, nslots, ntype, nmax, hoh, colli
 
 
 @pytest.mark.parametrize("waves", [8, 12])
-@pytest.mark.parametrize("kk,nslots,hoh,collinear", [(180, 15, False, True), (180, 15, True, True), (150, 31, True, False), (97, 1, False, False), (233, 30, False, False)])
+@pytest.mark.parametrize("kk,nslots,hoh,collinear", [(180, 15, False, True), (180, 15, True, True), (150, 31, True, False), (97, 3, False, False), (233, 30, False, False)])
 def test_split_tasks_equal_the_nine_tile_wave_bitwise(kk, nslots, hoh, collinear, waves):
     """Option s5_split = 3 (k_spmm5<., true, false, 3>: a wave takes a third of a group's nine tiles; persistent form of one-class operators)
     accumulates every tile in the same k order as the nine-tile wave: block Lanczos and Chebyshev results must be bitwise the same, on
