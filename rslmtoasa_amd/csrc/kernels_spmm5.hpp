@@ -57,6 +57,9 @@ namespace rsrec {
 #ifndef RSREC_S5_KSPLIT_PROBE
 #define RSREC_S5_KSPLIT_PROBE 0
 #endif
+#ifndef RSREC_S5_PRIO
+#define RSREC_S5_PRIO 0
+#endif
 #ifndef S5_WG_GROUPS
 #define S5_WG_GROUPS 4   // groups of 8 atoms per workgroup (x 2 spin waves each): 4 -> 512 threads
 #endif
@@ -741,6 +744,10 @@ __global__ __launch_bounds__(NSP == 3 ? 768 : S5_WG_GROUPS * 128) void k_spmm5(S
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sig = LDSA ? (int)((spin_by_xcd ? blockIdx.x : (blockIdx.x >> 3)) & 1) : wave / S5_WG_GROUPS, gslot = LDSA ? wave : wave % S5_WG_GROUPS;
+#if RSREC_S5_PRIO
+    // TIMING PROBE: static priority for the second-dispatched half of the workgroup's waves (the arbitration loser of a two-waves-per-SIMD kernel)
+    if (wave >= (int)(blockDim.x >> 7)) __builtin_amdgcn_s_setprio(1);
+#endif
     const int WGG = LDSA ? (int)(blockDim.x >> 6) : S5_WG_GROUPS;     // groups per workgroup (LDSA: one per wave; 8 waves, or 4 when the launch leaves half of the CU to other kernels)
     // several class runs in one persistent launch: this workgroup's run, and its place among the workgroups of that run
     int bxl = blockIdx.x, gdxl = gridDim.x, run_lo = D.run_lo, run_hi = D.run_hi, qrun = 0;
