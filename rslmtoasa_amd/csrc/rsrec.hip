@@ -109,6 +109,8 @@ struct rsrec_handle {
     Spmm5Operator orb_plain;                // h as ham_vec_matmul applies it when hoh is set (rsrec_orbital_moments, rsrec_apply_operator vel = 2)
     // work
     DevBuf d_green_in, d_green_out;   // rsrec_block_green
+    DevBuf d_kubo[5];                 // rsrec_kubo_moments: work vectors, left / right matrices, slice partials, moments -- kept between calls (tens of GB:
+                                      // their hipMalloc / hipFree cost 0.1-1.3 s per call on some boxes of the pool); given back when the recursion plans a batch
     DevBuf d_bsqrt, d_term, d_gim, d_ldos;   // LDOS stage on resident coefficients: sqrt(B^2), terminators, Im g0_jj, output images
     void* pin = nullptr;              // pinned host staging buffer: every per-call transfer goes through it (see xfer_*)
     size_t pin_bytes = 0;
@@ -116,6 +118,7 @@ struct rsrec_handle {
     // options
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
+    long opt_sat_pct = 100;      // a chain whose region holds at least this share (per cent) of the lattice runs on the list of ALL atoms (blocks outside the region are zero); rounds 1-3: 80 -- with a position-sorted list per level the superset no longer buys locality and costs its extra atoms (46^3: -1 %)
     long opt_s5_split = 0;       // persistent k_spmm5: 3 = a wave takes a third of a group's tiles (k_spmm5<., true, false, 3>; s5_waves = 8 / 12 / 16 waves per CU then)
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
     long opt_s5_spin_xcd = 0;    // persistent k_spmm5 on collinear operators: 1 = even XCDs serve output spin 0, odd XCDs spin 1; 0 = both spins on every XCD
@@ -388,7 +391,7 @@ extern "C" int rsrec_destroy(rsrec_t* h) {
     (void)rsrec_comm_destroy(h);
     h->d_comm.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_nbr, &h->d_nbr5, &h->d_s5queue, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
+    DevBuf* all[] = {&h->d_bsqrt, &h->d_term, &h->d_gim, &h->d_ldos, &h->d_green_in, &h->d_green_out, &h->d_kubo[0], &h->d_kubo[1], &h->d_kubo[2], &h->d_kubo[3], &h->d_kubo[4], &h->d_nbr, &h->d_nbr5, &h->d_s5queue, &h->d_iz, &h->d_hst, &h->d_hloc, &h->d_host, &h->d_holoc, &h->d_enim, &h->d_lsham, &h->d_vec[0], &h->d_vec[1],
                      &h->d_vec[2], &h->d_vec[3], &h->d_vec[4], &h->d_vec[5], &h->d_order, &h->d_cum, &h->d_partial, &h->d_partial2, &h->d_coefA, &h->d_coefB, &h->d_bmats,
                      &h->d_status, &h->d_frags, &h->d_seed, &h->d_seedcoef, &h->d_mu, &h->d_scal, &h->d_zsqr};
     for (auto b : all) b->release();
@@ -433,6 +436,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else if (!strcmp(key, "s5_split")) h->opt_s5_split = value;
+    else if (!strcmp(key, "sat_pct")) h->opt_sat_pct = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else if (!strcmp(key, "kubo_vbatch")) h->opt_kubo_vbatch = value;
     else if (!strcmp(key, "s5_host_emit")) h->opt_s5_host_emit = value;
@@ -705,6 +709,7 @@ struct BatchPlan {
 
 // how many chains are advanced together, and how many workgroups each gets
 int plan_batch(rsrec_t* h, int nchains, int nvec, size_t vec_elems_per_chain, BatchPlan& bp) {
+    for (auto& kb : h->d_kubo) kb.release();                     // (a Kubo call keeps its buffers for the next one; the recursion takes the memory back)
     size_t free_b = 0, total_b = 0;
     HIPCK(h, hipMemGetInfo(&free_b, &total_b));
     size_t reusable = 0;
@@ -741,7 +746,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
     // order -- on the per-level lists k_mfma_orth3 was 2.8 % slower (46^3, same box).  row = [level-major | per level | all atoms].
     const int cap = grouped ? kk + 7 * h->nmax + 7 * h->ntype + 8 : kk;          // capacity of one list of all atoms
     const int cap_pre = ((grouped ? kk + 7 * h->nmax + 7 * h->ntype * nlev + 8 : kk) + GROUP - 1) / GROUP * GROUP;   // capacity of the level-major list (a multiple of 8: every list starts on a group border)
-    const int flags = (two_pass ? 1 : 0) | (grouped ? 2 : 0) | (nseed << 2);
+    const int flags = (two_pass ? 1 : 0) | (grouped ? 2 : 0) | ((int)std::min<long>(100, std::max<long>(1, h->opt_sat_pct)) << 2) | (nseed << 9);
     for (auto* e : h->region_cache)
         if (e->epoch == h->lattice_epoch && e->nlev == nlev && e->napply == napply && e->flags == flags && (int)e->seeds.size() == nb * nseed &&
             std::equal(e->seeds.begin(), e->seeds.end(), seeds0)) {
@@ -753,7 +758,8 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
             return RSREC_OK;
         }
     const int ntau_h = h->nmax + h->ntype, nfs_h = h->nslots + 1;
-    const int sat_from = (int)(0.8 * kk);                        // regions of at least this many atoms run on the list of all atoms
+    const int sat_pct = (int)std::min<long>(100, std::max<long>(1, h->opt_sat_pct));
+    const int sat_from = (int)(0.01 * sat_pct * kk);            // regions of at least this many atoms run on the list of all atoms
     // the regions first (a few short-lived host threads; see below), then the row size they need
     std::vector<Region> regs(nb);
     auto run_threads = [&](auto&& fn) {
@@ -2457,6 +2463,7 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
     HIPCK(h, hipMemGetInfo(&free_b, &total_b));
     size_t reusable = 0;
     for (int v = 0; v < 6; ++v) reusable += h->d_vec[v].bytes;
+    for (auto& kb : h->d_kubo) reusable += kb.bytes;             // the buffers of the previous call (reused where they are large enough)
     const double budget = 0.9 * (double)(free_b + reusable);
     const int ksteps_total = (int)((NB * (size_t)kk + 3) / 4);            // k-steps of 4 rows (the last one may end inside the zero block)
     const int nbn_max = (nchunk * NB + KG_BLK - 1) / KG_BLK;
@@ -2482,11 +2489,15 @@ extern "C" int rsrec_kubo_moments(rsrec_t* h, int nvec, int nseed, const int32_t
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: %.1f GB needed for one left vector at a time on %d atoms, %.1f GB free", need_for(1, 1) * 1e-9, kk, free_b * 1e-9);
     for (int v = 0; v < 6; ++v) h->d_vec[v].release();
     const size_t sstride = (size_t)nbv * velems;                                // doubles between two slots of a buffer (nbv chains each)
-    DevBuf work, Lm, Rm, Part, Mu;
-    auto cleanup = [&]() { work.release(); Lm.release(); Rm.release(); Part.release(); Mu.release(); };
+    DevBuf &work = h->d_kubo[0], &Lm = h->d_kubo[1], &Rm = h->d_kubo[2], &Part = h->d_kubo[3], &Mu = h->d_kubo[4];
+    auto cleanup = [&]() {};                                      // the buffers stay with the handle for the next call
+    {   // buffers that have to grow are given back first, so that the new sizes are asked of the memory the budget counted on
+        const size_t want[5] = {11 * sstride * 8, (size_t)lchunk * sstride * 8, (size_t)nchunk * sstride * 8, (size_t)part_bytes(lchunk), (size_t)nbv * cond_ll * cond_ll * BLK * 16};
+        for (int q = 0; q < 5; ++q) if (h->d_kubo[q].bytes < want[q]) h->d_kubo[q].release();
+    }
     if (work.reserve(11 * sstride * 8) != hipSuccess || Lm.reserve((size_t)lchunk * sstride * 8) != hipSuccess || Rm.reserve((size_t)nchunk * sstride * 8) != hipSuccess ||
         Part.reserve((size_t)part_bytes(lchunk)) != hipSuccess || Mu.reserve((size_t)nbv * cond_ll * cond_ll * BLK * 16) != hipSuccess) {
-        cleanup();
+        for (auto& kb : h->d_kubo) kb.release();
         return fail(h, RSREC_ERR_DEVICE, "rsrec_kubo_moments: out of device memory");
     }
     HIPCK(h, hipMemsetAsync(Lm.p, 0, (size_t)lchunk * sstride * 8, h->stream));    // (block kk of every slot stays the zero block)
