@@ -2015,7 +2015,8 @@ extern "C" int rsrec_scalar_density(rsrec_t* h, int nsites, int nmdir, int llmax
     XFER(xfer_h2d(h, d_en, ene, eb));
     reset_timing(h);
     hipEvent_t e0 = next_event(h);
-    const int T = 64;
+    // one LDS column of 2 lld doubles per thread: as many threads per workgroup as 64 KB hold (64 up to lld = 64, one at lld = 4096)
+    const int T = (int)std::max<size_t>(1, std::min<size_t>(64, (64 * 1024) / (2 * (size_t)lld * sizeof(double))));
     const size_t lds = 2 * (size_t)lld * T * sizeof(double);
     if (lds > 64 * 1024) return fail(h, RSREC_ERR_ARG, "rsrec_scalar_density: lld = %d too deep for the band-edge kernel", lld);
     k_scalar_edges<<<(nchain + T - 1) / T, T, lds, h->stream>>>(lld, llmax, nchain, d_a, d_b, d_ed);

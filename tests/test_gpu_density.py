@@ -71,6 +71,21 @@ def test_density_matches_oracle_on_perturbed_chains_and_parameters(oracle_lib):
         rec.close()
 
 
+def test_density_on_deep_chains(oracle_lib):
+    """lld = 150 (the band-edge kernel then runs fewer threads per workgroup: one LDS column per thread): GPU against the CPU restatement."""
+    rng = np.random.default_rng(5)
+    p, rec = scalar_recursion("bccFe_nsp1_lanczos")
+    lld, n = 150, 3
+    a = np.asfortranarray(0.01 * rng.standard_normal((lld, 18, n, 1)))          # a weakly disordered chain: a band about [-1, 1]
+    b2 = np.asfortranarray(0.25 * (1.0 + 0.02 * rng.random((lld, 18, n, 1))))
+    ene = np.linspace(-1.2, 1.2, 97)
+    rec.a = a; rec.b2 = b2; rec.control.lld = lld
+    want = oracle_lib.scalar_density(a, b2, ene, np.ones((18, n)), np.zeros((18, n)), lld)
+    got = Green(rec, ene).density(nsites=n)
+    assert np.abs(want).max() > 0.1 and np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    rec.close()
+
+
 def test_density_argument_errors():
     p, rec = scalar_recursion("bccFe_nsp1_lanczos")
     gr = Green(rec, np.linspace(-1, 1, 5))

@@ -153,3 +153,32 @@ def test_left_matrix_in_chunks(name):
     finally:
         R.chebyshev_scaling = orig
     rec.close()
+
+
+def test_vector_batches_and_kept_buffers_do_not_change_a_vector():
+    """The vectors of a call advance together as the chains of every launch (up to 8) and the call's buffers stay with the handle: a
+    vector's moments must not depend on how many vectors share its launches (1, 3 in one batch, 11 in batches of 8 + 3, batches of 2),
+    nor on a recursion call in between (which takes the kept buffers back), nor on a larger call before a smaller one."""
+    z = load_golden("fccPt_kubo")
+    rec, p = make_rec(z)
+    import rslmtoasa_amd.recursion as R
+    orig = scaled(rec, z)
+    try:
+        kk = p["nn"].shape[0]
+        rng = np.random.default_rng(3)
+        nvec, cond_ll = 11, 4
+        seeds = np.tile(np.arange(1, kk + 1, dtype=np.int32), (nvec, 1))
+        coefs = np.exp(2j * np.pi * rng.random((nvec, kk))) / np.sqrt(kk)
+        kw = dict(vo_a=z.get("vo_a"), vo_b=z.get("vo_b"))
+        all11 = rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, seeds=seeds, coefs=coefs, **kw).copy()
+        one = rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, seeds=seeds[4:5], coefs=coefs[4:5], **kw).copy()
+        assert np.array_equal(one[..., 0], all11[..., 4])
+        rec.recur_b()                                              # the recursion plans its batch: the Kubo buffers are given back
+        three = rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, seeds=seeds[8:11], coefs=coefs[8:11], **kw).copy()
+        assert np.array_equal(three, all11[..., 8:11])
+        rec.set_option("kubo_vbatch", 2)
+        pairs = rec.compute_moments_stochastic(z["v_a"], z["v_b"], cond_ll, seeds=seeds[:5], coefs=coefs[:5], **kw)
+        assert np.array_equal(pairs, all11[..., :5])
+    finally:
+        R.chebyshev_scaling = orig
+    rec.close()
