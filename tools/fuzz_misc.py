@@ -55,7 +55,8 @@ def ragged(rng):
 def case_kubo(rng, seed):
     p, tag = ragged(rng)
     kk, ns, nt = p["nn"].shape[0], p["ee"].shape[2], p["ee"].shape[3]
-    cond_ll = int(rng.integers(2, 7)); nvec = int(rng.integers(1, 4)); nseed = int(rng.choice([1, 3, kk]))
+    cond_ll = int(rng.integers(2, 7)); nvec = int(rng.integers(1, 12)); nseed = int(rng.choice([1, 3, kk]))      # up to 8 vectors share a launch
+    vbatch, lchunk = int(rng.choice([0, 0, 1, 3])), int(rng.choice([0, 0, 1, 2]))
     blk = lambda: np.asfortranarray(0.2 * (rng.standard_normal((18, 18, ns, nt)) + 1j * rng.standard_normal((18, 18, ns, nt))))
     v_a, v_b = blk(), blk()
     vo_a, vo_b = (blk(), blk()) if p["hoh"] else (None, None)
@@ -63,12 +64,13 @@ def case_kubo(rng, seed):
     coefs = np.exp(2j * np.pi * rng.random((nvec, nseed))) / np.sqrt(nseed)
     emin, emax = -60.0, 60.0
     rec = Recursion(*objects_from(p, [1], cond_ll, emin=emin, emax=emax), device=0)
+    rec.set_option("kubo_vbatch", vbatch); rec.set_option("kubo_lchunk", lchunk)
     mu = rec.compute_moments_stochastic(v_a, v_b, cond_ll, vo_a=vo_a, vo_b=vo_b, seeds=seeds, coefs=coefs)
     rec.close()
     a, b = chebyshev_scaling(emin, emax)
     ref = oracle.Oracle(p).kubo_moments(seeds, coefs, cond_ll, a, b, v_a, v_b, vo_a, vo_b)
     err = max(np.abs(mu[..., i] - ref[..., i]).max() / max(np.abs(ref[..., i]).max(), 1e-300) for i in range(nvec))
-    return float(err), RTOL, tag + " cond_ll=%d nvec=%d nseed=%d" % (cond_ll, nvec, nseed)
+    return float(err), RTOL, tag + " cond_ll=%d nvec=%d nseed=%d vbatch=%d lchunk=%d" % (cond_ll, nvec, nseed, vbatch, lchunk)
 
 
 def case_apply(rng, seed):
