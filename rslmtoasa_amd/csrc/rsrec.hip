@@ -759,7 +759,7 @@ int upload_regions(rsrec_t* h, const int* seeds0, int nb, int nseed, int nlev, i
         }
     const int ntau_h = h->nmax + h->ntype, nfs_h = h->nslots + 1;
     const int sat_pct = (int)std::min<long>(100, std::max<long>(1, h->opt_sat_pct));
-    const int sat_from = (int)(0.01 * sat_pct * kk);            // regions of at least this many atoms run on the list of all atoms
+    const int sat_from = (int)(((long)sat_pct * kk + 99) / 100);   // regions of at least this many atoms run on the list of all atoms (100: only the whole lattice)
     // the regions first (a few short-lived host threads; see below), then the row size they need
     std::vector<Region> regs(nb);
     auto run_threads = [&](auto&& fn) {

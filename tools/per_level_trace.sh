@@ -14,7 +14,7 @@ f = glob.glob(os.path.join(out, "t", "*", "*kernel_trace.csv"))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 by = {}
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0].replace("void rsrec::", "").split("<")[0]
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rsrec::", "").split("<")[0]
     by.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 for k in ("k_spmm5", "k_mfma_adot", "k_mfma_orth3"):
     if k in by:
