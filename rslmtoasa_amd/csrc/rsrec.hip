@@ -1093,8 +1093,10 @@ void launch_s5_one(rsrec_t* h, dim3 grid, const SpmmDims& SD, const int* order, 
         // for the kernels of another stream (the HBM-bound post-hop passes of the other half batch)
         const unsigned thr = (queue && h->opt_s5_waves == 4) ? S5_WG_GROUPS * 64 : S5_WG_GROUPS * 128;
         if (queue && h->opt_s5_split == 3) {
-            const unsigned thr3 = 64u * (unsigned)std::min<long>(16, std::max<long>(8, h->opt_s5_waves));
-            k_spmm5<TWO, true, false, 3><<<g2, thr3, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
+            const unsigned thr3 = 64u * (unsigned)std::min<long>(12, std::max<long>(8, h->opt_s5_waves));       // (launch bounds: 768 threads)
+            // the split stream requests its operands five steps ahead: up to two triples past the stream's end (never used) -- one more triple of LDS where it fits
+            const size_t lds3 = std::min(lds_limit, lds_bytes + (size_t)S5_TRIPLE_BYTES);
+            k_spmm5<TWO, true, false, 3><<<g2, thr3, lds3, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
         } else
         k_spmm5<TWO, true><<<g2, thr, lds_bytes, h->stream>>>(SD, order, cum, h->d_nbr5.as<int>(), iz, op.frag_set(set), op.meta_set(set), op.ntr, in, out, in2, nullptr, ntau, one, queue, spin_by_xcd, epi);
     } else
