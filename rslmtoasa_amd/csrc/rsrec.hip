@@ -1256,11 +1256,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     h->res_kind = 0;
     HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
+    // matrix-core set without hoh: vector 1 (pmn of the VALU set, h psi of the hoh passes) is not used by the u-scheme -- it is neither allocated
+    // nor cleared (32 GB and a 5 ms memset per call for 64 sites of the 10^5-atom cell).  (Vector 2, H psi, stays cleared: leaving that out as
+    // well made dying chains of the fuzz seeds survive on recycled device memory -- tests/test_gpu_breakdown.py in the full suite.)
+    const bool use_v1 = !MFMA || hoh;
     BatchPlan bp;
-    int rc = plan_batch(h, nchains, nvec, velems / 2, bp);
+    int rc = plan_batch(h, nchains, nvec - (use_v1 ? 0 : 1), velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
-    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
+    for (int v = 0; v < nvec; ++v) if (v != 1 || use_v1) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     const size_t gram_elems = (size_t)B * 256 * 1296;                                  // doubles: Gram partials of one kernel (<= 256 workgroups per chain)
     HIPCK(h, h->d_partial.reserve(std::max((size_t)B * std::max(nblk * 2, 256) * 2 * BLK * sizeof(double2), 2 * gram_elems * sizeof(double))));
     h->p2_slot = (size_t)B * 16 * 2 * 1296;
@@ -1356,7 +1360,8 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         // (each SCF iteration of the reference: recur_b on the same <= 4 sites) -- 49 levels x 6-8 dependent launches otherwise cost
         // more host time than device time (13 ms for one site of the 22^3 cell, two thirds of it launch latency).
         auto enqueue_levels = [&]() -> int {
-            for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+            for (int v = 0; v < nvec; ++v)
+                if (v != 1 || use_v1) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
             HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
             HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
             if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
