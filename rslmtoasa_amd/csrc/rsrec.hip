@@ -1257,8 +1257,9 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     // matrix-core set without hoh: vector 1 (pmn of the VALU set, h psi of the hoh passes) is not used by the u-scheme -- it is neither allocated
-    // nor cleared (32 GB and a 5 ms memset per call for 64 sites of the 10^5-atom cell).  (Vector 2, H psi, stays cleared: leaving that out as
-    // well made dying chains of the fuzz seeds survive on recycled device memory -- tests/test_gpu_breakdown.py in the full suite.)
+    // nor cleared (32 GB and a 5 ms memset per call for 64 sites of the 10^5-atom cell).  (Vector 2, H psi, stays cleared although the SpMM
+    // writes every atom the passes behind it read: those passes run padding entries of the lists as the zero block kk, which has to BE zero
+    // in every vector -- left uncleared on recycled device memory, dying chains of the fuzz seeds survived, tests/test_gpu_breakdown.py.)
     const bool use_v1 = !MFMA || hoh;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec - (use_v1 ? 0 : 1), velems / 2, bp);
