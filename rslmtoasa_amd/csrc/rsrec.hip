@@ -1257,9 +1257,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     HIPCK(h, h->d_coefA.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     HIPCK(h, h->d_coefB.reserve((size_t)nchains * lld * BLK * sizeof(double2)));
     // matrix-core set without hoh: vector 1 (pmn of the VALU set, h psi of the hoh passes) is not used by the u-scheme -- it is neither allocated
-    // nor cleared (32 GB and a 5 ms memset per call for 64 sites of the 10^5-atom cell).  (Vector 2, H psi, stays cleared although the SpMM
-    // writes every atom the passes behind it read: those passes run padding entries of the lists as the zero block kk, which has to BE zero
-    // in every vector -- left uncleared on recycled device memory, dying chains of the fuzz seeds survived, tests/test_gpu_breakdown.py.)
+    // nor cleared (32 GB and a 5 ms memset per call for 64 sites of the 10^5-atom cell).  Of vector 2, H psi, only the zero block kk is
+    // cleared: the SpMM writes every atom the passes behind it read, but those passes run padding entries of the lists as the zero block,
+    // which has to BE zero in every vector (left uncleared on recycled device memory, dying chains of the fuzz seeds survived:
+    // tests/test_gpu_breakdown.py).  46^3 x 64 sites: 2 387 -> 2 361-2 381 ms per step.
     const bool use_v1 = !MFMA || hoh;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec - (use_v1 ? 0 : 1), velems / 2, bp);
@@ -1361,8 +1362,15 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         // (each SCF iteration of the reference: recur_b on the same <= 4 sites) -- 49 levels x 6-8 dependent launches otherwise cost
         // more host time than device time (13 ms for one site of the 22^3 cell, two thirds of it launch latency).
         auto enqueue_levels = [&]() -> int {
-            for (int v = 0; v < nvec; ++v)
-                if (v != 1 || use_v1) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+            for (int v = 0; v < nvec; ++v) {
+                if (v == 1 && !use_v1) continue;
+                if (v == 2 && !use_v1) {
+                    // H psi: only its zero block (one 2-D memset over the chains); every other block is written by the SpMM before it is read
+                    HIPCK(h, hipMemset2DAsync(static_cast<char*>(h->d_vec[v].p) + (size_t)kk * BLD * sizeof(double), velems * sizeof(double), 0, BLD * sizeof(double), (size_t)nb, h->stream));
+                    continue;
+                }
+                HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+            }
             HIPCK(h, hipMemsetAsync(dA, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
             HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
             if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
