@@ -2174,11 +2174,14 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
     // memory, so a call over many sites (nrec ~ kk) sizes its vectors around them instead of failing behind them
     h->res_kind = 0;
     HIPCK(h, h->d_mu.reserve((size_t)nsites * nmom * BLK * sizeof(double2)));
+    // with the Chebyshev step fused into the SpMM's epilogue (the default of the matrix-core set) H psi is never held: vector 3 is neither
+    // allocated nor cleared
+    const bool use_v3 = !(mf_cheb && (hoh || use_kp) && h->opt_cheb_fused);
     BatchPlan bp;
-    rc = plan_batch(h, nsites, nvec, velems / 2, bp);
+    rc = plan_batch(h, nsites, nvec - (use_v3 ? 0 : 1), velems / 2, bp);
     if (rc) return rc;
     const int B = bp.batch, nblk = bp.nblk;
-    for (int v = 0; v < nvec; ++v) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
+    for (int v = 0; v < nvec; ++v) if (v != 3 || use_v3) HIPCK(h, h->d_vec[v].reserve((size_t)B * velems * sizeof(double)));
     HIPCK(h, h->d_partial.reserve(std::max((size_t)B * nblk * 2 * BLK * sizeof(double2), (size_t)B * 256 * 2 * 1296 * sizeof(double))));
     h->p2_slot = (size_t)B * 16 * 2 * 1296;
     HIPCK(h, h->d_partial2.reserve(2 * h->p2_slot * sizeof(double)));
@@ -2232,7 +2235,7 @@ int run_chebyshev(rsrec_t* h, int nsites, int nseed, const int32_t* seed_atoms, 
         CV.order = h->cur_order; CV.cum = h->cur_cum; CV.obase = h->cur_cum + (size_t)h->cur_nrows * nlev; CV.nlev = nlev; CV.vstride = velems; CV.cpo = 1; CV.ostride = ostride;
         ChainView CVp = CV;                                   // the streaming moment pass walks the level-major lists (upload_regions)
         CVp.cum = h->cur_cum + (size_t)2 * h->cur_nrows * nlev; CVp.obase = h->cur_cum + (size_t)3 * h->cur_nrows * nlev;
-        for (int v = 0; v < nvec; ++v) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
+        for (int v = 0; v < nvec; ++v) if (v != 3 || use_v3) HIPCK(h, hipMemsetAsync(h->d_vec[v].p, 0, (size_t)nb * velems * sizeof(double), h->stream));
         HIPCK(h, hipMemsetAsync(mu, 0, (size_t)nb * mstride * sizeof(double2), h->stream));
         double* p0 = h->d_vec[0].as<double>();
         double* p1 = h->d_vec[1].as<double>();
