@@ -283,6 +283,7 @@ int rsrec_comm_destroy(rsrec_t *h);
  *   "s5_octet"   atoms with their own operator blocks (nmax) from which their groups are formed over 8 CHAINS of the batch (they then share
  *                the atom's operator fragments the way 8 atoms of a type do) once every chain's region covers the lattice; 0 = never [8]
  *   "s5_host_emit" 1 = swizzle k_spmm5's operator streams on the host instead of assembling them on the device (cross-check) [0]
+ *   "orth_oop"   1 = the orthogonalisation pass writes u_{n+1} into a third u vector instead of over u_{n-1} (faster on the HBM, one more work vector) [1]
  *   "sat_pct"    a chain whose region holds at least this share (per cent) of the lattice runs on the list of ALL atoms instead of its own [100]
  *   "kubo_lchunk" rsrec_kubo_moments: left vectors held on the device at a time [0 = as many as fit];  "kubo_vbatch" vectors of a call advanced
  *                together as the chains of every launch [0 = up to 8, as many as fit beside a whole left matrix each] */

@@ -86,7 +86,8 @@ __device__ __forceinline__ void u3_mac(double4_t& ca, double4_t& cb, double& cr,
 // LayoutRM and CI vectors alike (the tables carry the column meaning); 3 block reads + 1 block write per atom-step.
 __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, int level, int zero_block, const double* __restrict__ tvec,
                                                                 const double* __restrict__ ucur, double* uprev,
-                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/) {
+                                                                const double* __restrict__ tabs, double* partial /*[chain][nblk][1296]*/,
+                                                                double* unext = nullptr /*where u_{n+1} goes (nullptr: over u_{n-1})*/) {
     __shared__ double lds[MF_WAVES * 1296];
     const int chain = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
     const double* tv = tvec + vo;
     const double* uc = ucur + vo;
     double* up = uprev + vo;
+    double* uo = (unext ? unext : uprev) + vo;
     const int l15 = lane & 15, l4 = lane >> 4, l3 = lane & 3, lg = (lane >> 2) & 3;
     double T1[27], T2[27], T3[27];
     {
@@ -154,10 +156,10 @@ __global__ __launch_bounds__(MF_WAVES * 64, 1) void k_mfma_orth3(ChainView CV, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const RowRef rs = tile_row(P.ta, 16 * P.mt + l4 + 4 * j);
-            if (rs.valid) { st_stream(up + rs.off + l15, (double)P.ca[j]); st_stream(up + rs.off + 16 + l15, (double)P.cb[j]); }
+            if (rs.valid) { st_stream(uo + rs.off + l15, (double)P.ca[j]); st_stream(uo + rs.off + 16 + l15, (double)P.cb[j]); }
         }
         const RowRef rr = tile_row(P.ta, 16 * P.mt + 4 * lg + l4);
-        if (rr.valid) st_stream(up + rr.off + 32 + l3, P.cr);
+        if (rr.valid) st_stream(uo + rr.off + 32 + l3, P.cr);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double f0 = P.ca[j], f1 = P.cb[j];

@@ -119,6 +119,7 @@ struct rsrec_handle {
     long opt_batch = 0, opt_kernels = 0, opt_nblk = 0, opt_spmm5 = 2, opt_chain_fold = 1, opt_s5_cap = 0, opt_side = 1, opt_s5_lds = 1, opt_s5_queue = 1, opt_cheb_fused = 1;
     long opt_s5_waves = 8;
     long opt_sat_pct = 100;      // a chain whose region holds at least this share (per cent) of the lattice runs on the list of ALL atoms (blocks outside the region are zero); rounds 1-3: 80 -- with a position-sorted list per level the superset no longer buys locality and costs its extra atoms (46^3: -1 %)
+    long opt_orth_oop = 1;       // 1 = k_mfma_orth3 writes u_{n+1} into a third u vector instead of over u_{n-1} (faster on the HBM; one more work vector)
     long opt_s5_split = 0;       // persistent k_spmm5: 3 = a wave takes a third of a group's tiles (k_spmm5<., true, false, 3>; s5_waves = 8 / 12 / 16 waves per CU then)
     long opt_s5_run_min = 0;     // operators with several classes: smallest class run (in groups) that gets an LDS launch of its own (0: by launch size)
     long opt_s5_spin_xcd = 0;    // persistent k_spmm5 on collinear operators: 1 = even XCDs serve output spin 0, odd XCDs spin 1; 0 = both spins on every XCD
@@ -436,6 +437,7 @@ extern "C" int rsrec_set_option(rsrec_t* h, const char* key, long value) {
     else if (!strcmp(key, "orth3")) h->opt_orth3 = value;
     else if (!strcmp(key, "s5_waves")) h->opt_s5_waves = value;
     else if (!strcmp(key, "s5_split")) h->opt_s5_split = value;
+    else if (!strcmp(key, "orth_oop")) h->opt_orth_oop = value;
     else if (!strcmp(key, "sat_pct")) h->opt_sat_pct = value;
     else if (!strcmp(key, "kubo_lchunk")) h->opt_kubo_lchunk = value;
     else if (!strcmp(key, "kubo_vbatch")) h->opt_kubo_vbatch = value;
@@ -1261,7 +1263,13 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
     // cleared: the SpMM writes every atom the passes behind it read, but those passes run padding entries of the lists as the zero block,
     // which has to BE zero in every vector (left uncleared on recycled device memory, dying chains of the fuzz seeds survived:
     // tests/test_gpu_breakdown.py).  46^3 x 64 sites: 2 387 -> 2 361-2 381 ms per step.
-    const bool use_v1 = !MFMA || hoh;
+    // u_{n+1} goes into a THIRD u vector instead of over u_{n-1} (option orth_oop, round 4): k_mfma_orth3 then reads three vectors and writes a
+    // fourth one -- 64 x 46^3: 25.7 -> 24.5 ms per saturated level (the in-place pass alternated 26.3 / 25.0 with the level's parity, the out-of-place
+    // one cycles 25.0 / 25.6 / 22.9 with the three arrangements of its buffers), the step 2 387 -> 2 361 ms, 22^3 387 -> 379 ms; bitwise the same results.
+    // The vector is number 1 without hoh (unused by the u-scheme otherwise) and number 4 with hoh (vector 1 holds h psi of the first pass).
+    const bool oop = MFMA && h->opt_orth_oop != 0 && h->opt_orth3 != 2;
+    if (oop && hoh) nvec = 5;
+    const bool use_v1 = !MFMA || hoh || oop;
     BatchPlan bp;
     int rc = plan_batch(h, nchains, nvec - (use_v1 ? 0 : 1), velems / 2, bp);
     if (rc) return rc;
@@ -1364,7 +1372,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
         auto enqueue_levels = [&]() -> int {
             for (int v = 0; v < nvec; ++v) {
                 if (v == 1 && !use_v1) continue;
-                if (v == 2 && !use_v1) {
+                if (v == 2 && MFMA && !hoh) {
                     // H psi: only its zero block (one 2-D memset over the chains); every other block is written by the SpMM before it is read
                     HIPCK(h, hipMemset2DAsync(static_cast<char*>(h->d_vec[v].p) + (size_t)kk * BLD * sizeof(double), velems * sizeof(double), 0, BLD * sizeof(double), (size_t)nb, h->stream));
                     continue;
@@ -1375,6 +1383,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
             HIPCK(h, hipMemsetAsync(dB, 0, (size_t)nb * cstride * sizeof(double2), h->stream));
             if (MFMA) HIPCK(h, hipMemsetAsync(bfrags, 0, (size_t)nb * 3 * 27 * 64 * sizeof(double), h->stream));
             psi = h->d_vec[0].as<double>(); t2 = h->d_vec[3].as<double>();   // (swapped every level)
+            double* t3 = oop ? h->d_vec[hoh ? 4 : 1].as<double>() : nullptr;
             if (ci) k_seed<LayoutCI><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
             else k_seed<L><<<nb, 64, 0, h->stream>>>(psi, velems, h->d_seed.as<int>(), h->d_seedcoef.as<double2>(), nseed);
             k_set_identity<<<nb, 256, 0, h->stream>>>(dB, cstride);                                  // b2temp_b(:,:,1) = I  (:1837)
@@ -1432,9 +1441,10 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                       rc = wait_b_level(); if (rc) return rc;
                       k_reduce_a_u<<<nb, 1024, 0, h->stream>>>(p2, n2, dA + (size_t)ll * BLK, cstride, h->d_bmats.as<double2>(), bfrags, ci); }
                     if (h->opt_orth3 == 2) k_mfma_orth3w<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
-                else k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, hpsi, psi, t2, bfrags, gp_b);
+                else k_mfma_orth3<<<gl, MF_WAVES * 64, 0, h->stream>>>(CVp, lv_final, kk, hpsi, psi, t2, bfrags, gp_b, t3);
                     rc = reduce_b_level(gl.x, ll); if (rc) return rc;
-                    std::swap(psi, t2);
+                    if (oop) { double* f = t2; t2 = psi; psi = t3; t3 = f; }      // u_{n+1} is in t3; the vector of u_{n-1} is free
+                    else std::swap(psi, t2);
                     hop_ev.emplace_back(e0, e1);
                     h->n_hop_launch += hoh ? 2 : 1;
                     continue;
@@ -1472,7 +1482,7 @@ int run_block_lanczos(rsrec_t* h, int nchains, int nseed, const int32_t* seed_at
                                           (uintptr_t)h->s4_op.frag_set(0), (uintptr_t)h->s4_op.meta_set(0), (uintptr_t)h->d_nbr.p, (uintptr_t)h->d_nbr5.p, (uintptr_t)h->d_iz.p,
                                           (uintptr_t)h->d_partial.p, (uintptr_t)h->d_partial2.p, (uintptr_t)h->d_frags.p, (uintptr_t)dA, (uintptr_t)dB, (uintptr_t)h->d_bmats.p,
                                           (uintptr_t)h->d_status.p, (uintptr_t)h->d_seed.p, (uintptr_t)h->d_seedcoef.p, (uintptr_t)h->d_la_extra.p, (uintptr_t)h->d_s5queue.p,
-                                          (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
+                                          (uintptr_t)h->opt_side, (uintptr_t)h->opt_orth3, (uintptr_t)h->opt_orth_oop, (uintptr_t)h->opt_nblk, (uintptr_t)h->opt_spmm5, (uintptr_t)h->opt_s5_lds, (uintptr_t)h->opt_s5_queue, (uintptr_t)h->opt_s5_run_min, (uintptr_t)h->cur_entry,
                                           (uintptr_t)h->opt_chain_fold, (uintptr_t)h->opt_s5_cap, (uintptr_t)h->p2_slot, (uintptr_t)OP.single_class(0), (uintptr_t)OP.spin_mixing, (uintptr_t)h->opt_s5_octet, (uintptr_t)h->opt_s5_spin_xcd,
                                           (uintptr_t)h->lattice_epoch, (uintptr_t)OP.sched_epoch, (uintptr_t)h->nslots, (uintptr_t)h->nmax, (uintptr_t)h->ntype, (uintptr_t)h->hslots,
                                           (uintptr_t)h->opt_s5_waves, (uintptr_t)h->opt_s5_split, (uintptr_t)h->opt_batch, (uintptr_t)B, (uintptr_t)h->opt_kernels, (uintptr_t)h->n_cu};

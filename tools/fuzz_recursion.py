@@ -14,7 +14,7 @@ from oracle import oracle
 from rslmtoasa_amd.recursion import Recursion, chebyshev_scaling
 
 OPTIONS = {"kernels": (0, 1, 2), "spmm5": (0, 1, 2), "s5_lds": (0, 1, 2), "s5_queue": (0, 1, 2), "s5_run_min": (0, 1), "graph": (0, 1, 2), "orth3": (1, 2),
-           "batch": (0, 1, 3), "chain_fold": (1, 2), "s5_host_emit": (0, 1), "s5_octet": (0, 1, 1), "s5_spin_xcd": (0, 1), "side_stream": (0, 1), "cheb_fused": (0, 1), "s5_waves": (4, 8, 12), "s5_split": (0, 3), "sat_pct": (40, 80, 100)}
+           "batch": (0, 1, 3), "chain_fold": (1, 2), "s5_host_emit": (0, 1), "s5_octet": (0, 1, 1), "s5_spin_xcd": (0, 1), "side_stream": (0, 1), "cheb_fused": (0, 1), "s5_waves": (4, 8, 12), "s5_split": (0, 3), "sat_pct": (40, 80, 100), "orth_oop": (0, 1)}
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
